@@ -1,0 +1,71 @@
+"""ctypes binding of libvitk.so -- the C-ABI boundary declared in include/vitk.h.
+
+There is NO fallback: if the library is missing or a call fails, the op raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libvitk.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
+
+_lib = None
+
+c_int, c_long, c_float, c_vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+
+_SIGNATURES = {
+    'vitk_version': ([], c_int),
+    'vitk_last_error': ([], ctypes.c_char_p),
+    'vitk_gemm': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                   c_vp, c_long, c_vp, c_long, c_vp, c_long,
+                   c_vp, c_int, c_vp, c_vp, c_long,
+                   c_vp, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    'vitk_layernorm_fwd': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_vp, c_float, c_vp, c_long,
+                            c_vp, c_vp, c_vp], c_int),
+    'vitk_layernorm_bwd': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp,
+                            c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp], c_int),
+    'vitk_colsum': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_vp], c_int),
+    'vitk_cast': ([c_int, c_long, c_vp, c_vp, c_vp], c_int),
+    'vitk_patchify': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp], c_int),
+    'vitk_unpatchify': ([c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp], c_int),
+    'vitk_cls_rows': ([c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp], c_int),
+    'vitk_token_grads': ([c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp], c_int),
+    'vitk_attn_fwd': ([c_int, c_int, c_int, c_int, c_int,
+                       c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long,
+                       c_float, c_int, c_vp, c_long, c_vp, c_vp], c_int),
+    'vitk_attn_bwd': ([c_int, c_int, c_int, c_int, c_int,
+                       c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long,
+                       c_float, c_int, c_vp, c_vp, c_long, c_vp,
+                       c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_vp], c_int),
+    'vitk_favor_features_fwd': None,   # declared when favor.hip lands
+}
+
+
+class VitkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvitk.so (once).  Raises if it has not been built: there is no other path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VitkError(f'{LIB_PATH} is missing: run `python -m vit_amd._build` (hipcc, gfx950) first')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, sig in _SIGNATURES.items():
+            if sig is None:
+                continue
+            if not hasattr(L, name):
+                continue
+            fn = getattr(L, name)
+            fn.argtypes, fn.restype = sig
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().vitk_last_error()
+        raise VitkError(f'{what} failed (status {status}): {msg.decode() if msg else "?"}')

@@ -1,0 +1,141 @@
+// Shared device helpers for the vitk kernels (gfx950 / CDNA4 only).
+//
+// Every MFMA kernel in this library is templated on the element type T in {float, __bf16} and
+// shares one fragment convention, so the fp32 parity path and the bf16 speed path run the SAME
+// code with a different instruction underneath:
+//
+//   Frag<T>  = 8 K-consecutive elements of ONE row, held by lane l for
+//              row (l & 15) and k = 8*(l >> 4) + e, e = 0..7, of a 32-deep K block.
+//   mma<T>   = D[4*(l>>4)+j][l&15] += sum_k A[.][k] * B[k][.]   (16x16 tile, K = 32)
+//              bf16: one v_mfma_f32_16x16x32_bf16
+//              f32 : eight v_mfma_f32_16x16x4_f32, step e consuming element e of both
+//                    fragments (lane group g then covers k = 8g+e: a permutation of the K
+//                    order inside the block, identical for A and B, hence the same sum).
+//              The f32 form is an exact k-ordered fmaf chain (MI355X guide, "FP32-input MFMA").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vitk {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+enum { VITK_F32 = 0, VITK_BF16 = 1 };
+
+template <typename T> struct Frag;
+template <> struct Frag<__bf16> {
+    bf16x8 v;
+};
+template <> struct Frag<float> {
+    float v[8];
+};
+
+__device__ __forceinline__ void frag_zero(Frag<__bf16>& f) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = (__bf16)0.0f;
+}
+__device__ __forceinline__ void frag_zero(Frag<float>& f) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = 0.0f;
+}
+
+// D(16x16) += A(16x32) * B(32x16); a = A rows on lanes, b = B columns on lanes.
+__device__ __forceinline__ f32x4 mma(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const Frag<float>& a, const Frag<float>& b, f32x4 acc) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b.v[e], acc, 0, 0, 0);
+    return acc;
+}
+
+// 8 K-contiguous elements from a (16-byte aligned) pointer, LDS or global.
+__device__ __forceinline__ void frag_load(Frag<__bf16>& f, const __bf16* p) {
+    f.v = *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f.v[e] = a[e];
+        f.v[4 + e] = b[e];
+    }
+}
+
+// Fragment from a K-MAJOR LDS image img[k][col] (row stride `ld` elements): lane l gets
+// img[8*(l>>4)+e][col0 + (l&15)], e = 0..7.  bf16 uses the hardware transpose read
+// (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies the address of row q, columns
+// 4p..4p+3; lane i receives column i of the 4 rows) and needs EXEC all ones, 8-byte aligned
+// addresses.  `base` points at img[k0][col0]; k0, col0*sizeof(T) multiples of 8 bytes.
+__device__ __forceinline__ void frag_load_kmajor(Frag<__bf16>& f, const __bf16* base, int ld, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int q = i >> 2, p = i & 3;
+    const __bf16* a0 = base + (8 * g + q) * ld + 4 * p;
+    const __bf16* a1 = a0 + 4 * ld;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    f.v = __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ void frag_load_kmajor(Frag<float>& f, const float* base, int ld, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = base[(8 * g + e) * ld + i];
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace vitk
+
+// ---- host side -------------------------------------------------------------------------
+#define VITK_OK 0
+#define VITK_ERR_ARG 1      // bad argument (shape / alignment / null pointer)
+#define VITK_ERR_LAUNCH 2   // HIP launch error
+#define VITK_ERR_WORKSPACE 3
+
+extern "C" void vitk_set_error(const char* fmt, ...);
+
+#define VITK_CHECK_ARG(cond, ...)        \
+    do {                                 \
+        if (!(cond)) {                   \
+            vitk_set_error(__VA_ARGS__); \
+            return VITK_ERR_ARG;         \
+        }                                \
+    } while (0)
+
+#define VITK_CHECK_LAUNCH(what)                                              \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) {                                             \
+            vitk_set_error("%s: HIP error %s", what, hipGetErrorString(e__)); \
+            return VITK_ERR_LAUNCH;                                          \
+        }                                                                    \
+    } while (0)

@@ -1,0 +1,420 @@
+// MFMA GEMM with fused epilogues: C = epilogue(alpha * op(A) * op(B) + bias) [+ residual].
+//
+// Replaces the aten addmm / bmm calls behind every nn.Linear on the reference hot path
+// (qkv/proj/fc1/fc2: timm_classes/timm_locality_aware_transformer.py:48,77 + timm Mlp;
+// query/key/value_proj, dense_AttnOut, dense_intermediate, dense_out:
+// disentangled_transformer.py:854-856,188,184,194; patch-embed conv model.py:92) and their
+// autograd backward (dX = dY W, dW = dY^T X).
+//
+// One kernel template serves all of them:
+//   * T in {__bf16, float}: bf16 uses v_mfma_f32_16x16x32_bf16, float the exact
+//     v_mfma_f32_16x16x4_f32 (common.h); accumulation is always fp32.
+//   * each operand is either K-contiguous in memory (rows of op(X) are contiguous along K;
+//     LDS image [row][K], XOR-swizzled 16-byte chunks, read with ds_read_b128) or K-major
+//     (LDS image [k][row] padded, bf16 fragments via ds_read_b64_tr_b16).  That covers
+//     NT (forward), NN (dX) and TN (dW) without any transposed copy in HBM.
+//   * 128x128 output tile per 256-thread workgroup (4 waves, 64x64 each = 4x4 MFMA tiles),
+//     128 bytes of K per step (64 bf16 / 32 f32), LDS double-buffered, global->register
+//     prefetch of step t+1 issued before the MFMAs of step t and written to LDS after them.
+//   * MFMA operands are swapped (D = B_frag x A_frag) so each lane owns 4 CONSECUTIVE output
+//     columns of one row: bias/aux/residual/C move as 8- or 16-byte vectors.
+//   * split-K (fp32 atomics) for the dW shapes whose output has too few tiles to fill 256 CUs.
+//   * XCD-aware, grouped tile order: workgroups that share an A row panel / B column panel
+//     run on the same XCD (private L2) back to back.
+#include "common.h"
+
+namespace vitk {
+
+constexpr int BM = 128, BN = 128;
+constexpr int STAGE_BYTES = 18432;  // max(KC image 128 rows x 128 B, KM image BK rows x 288|576 B)
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_DGELU = 3, ACT_DRELU = 4 };
+
+struct GemmParams {
+    const void* A;
+    const void* B;
+    void* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    const float* bias;     // [N] fp32 or null
+    int act;
+    const void* aux_in;    // act 3/4: pre-activation (dgelu) or activation output (drelu), dtype T
+    void* aux_out;         // act 1: pre-activation copy, dtype T
+    long ld_aux;
+    const void* residual;  // dtype T, added after the activation
+    long ldr;
+    int res_period;        // 0: residual row = output row; >0: row = res_off + (r % res_period)
+    int res_off;
+    int grp_rows;          // 0: identity; >0: out row = (r / grp_rows) * grp_stride + grp_off + r % grp_rows
+    int grp_stride, grp_off;
+    int accumulate;        // C += (fp32 C only)
+    int splitk;
+    int a_vec_ok, b_vec_ok;  // 16-byte vector loads legal (base + ld aligned)
+    int c_vec_ok;            // vector epilogue legal (C/aux/residual bases + lds aligned, N % 4 == 0)
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+template <typename T> struct Cfg {
+    static constexpr int EPC = 16 / sizeof(T);          // elements per 16-byte chunk
+    static constexpr int BK = 128 / sizeof(T);          // K elements per step
+    static constexpr int KB = BK / 32;                  // 32-deep MFMA blocks per step
+    static constexpr int KM_STRIDE = (128 * sizeof(T) + 32 * (sizeof(T) / 2)) / sizeof(T);  // 144 bf16 / 144 f32 elems
+    static constexpr int KM_CPR = 128 / EPC;            // chunks per k-row of the K-major image
+};
+static_assert(Cfg<__bf16>::KM_STRIDE * 2 == 288 && Cfg<float>::KM_STRIDE * 4 == 576, "km stride");
+static_assert(Cfg<__bf16>::BK * 288 <= STAGE_BYTES && Cfg<float>::BK * 576 <= STAGE_BYTES, "stage size");
+
+template <typename T>
+__device__ __forceinline__ u32x4 load_chunk(const T* p, int valid, bool vec_ok) {
+    constexpr int EPC = Cfg<T>::EPC;
+    if (valid >= EPC && vec_ok) return *reinterpret_cast<const u32x4*>(p);
+    union {
+        T e[EPC];
+        u32x4 v;
+    } u;
+    u.v = u32x4{0, 0, 0, 0};
+    if (valid > 0) {
+#pragma unroll
+        for (int i = 0; i < EPC; ++i)
+            if (i < valid) u.e[i] = p[i];
+    }
+    return u.v;
+}
+
+// Stage one operand tile (1024 16-byte chunks, 4 per thread) global -> registers.
+template <typename T, bool KM>
+__device__ __forceinline__ void stage_load(u32x4 (&r)[4], const T* __restrict__ X, long ld, int row0, int R,
+                                           int k0, int kend, bool vec_ok, int tid) {
+    constexpr int EPC = Cfg<T>::EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        if (!KM) {
+            const int row = c >> 3, ch = c & 7;
+            const int gr = row0 + row, gk = k0 + ch * EPC;
+            const int valid = (gr < R) ? min(EPC, kend - gk) : 0;
+            r[i] = load_chunk<T>(X + (long)gr * ld + gk, valid, vec_ok);
+        } else {
+            constexpr int CPR = Cfg<T>::KM_CPR;
+            const int krow = c / CPR, ch = c % CPR;
+            const int gk = k0 + krow, gc = row0 + ch * EPC;
+            const int valid = (gk < kend) ? min(EPC, R - gc) : 0;
+            r[i] = load_chunk<T>(X + (long)gk * ld + gc, valid, vec_ok);
+        }
+    }
+}
+
+template <typename T, bool KM>
+__device__ __forceinline__ void stage_store(const u32x4 (&r)[4], char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        int off;
+        if (!KM) {
+            const int row = c >> 3, ch = c & 7;
+            off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+        } else {
+            constexpr int CPR = Cfg<T>::KM_CPR;
+            const int krow = c / CPR, ch = c % CPR;
+            off = krow * (Cfg<T>::KM_STRIDE * (int)sizeof(T)) + (ch << 4);
+        }
+        *reinterpret_cast<u32x4*>(lds + off) = r[i];
+    }
+}
+
+// Fragment for tile rows [row_base, row_base+16) and MFMA K block kb of the staged image.
+template <typename T, bool KM>
+__device__ __forceinline__ void read_frag(Frag<T>& f, const char* lds, int row_base, int kb, int lane) {
+    if (!KM) {
+        const int row = row_base + (lane & 15), g = lane >> 4;
+        const int sw = (row >> 1) & 7;
+        if (sizeof(T) == 2) {
+            const int ch = kb * 4 + g;
+            frag_load(f, reinterpret_cast<const T*>(lds + row * 128 + ((ch ^ sw) << 4)));
+        } else {
+            // 8 floats = chunks 2g and 2g+1; the swizzle may separate them
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + row * 128 + (((2 * g) ^ sw) << 4));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + row * 128 + (((2 * g + 1) ^ sw) << 4));
+            float* fv = reinterpret_cast<float*>(&f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                fv[e] = a[e];
+                fv[4 + e] = b[e];
+            }
+        }
+    } else {
+        const T* base = reinterpret_cast<const T*>(lds) + (kb * 32) * Cfg<T>::KM_STRIDE + row_base;
+        frag_load_kmajor(f, base, Cfg<T>::KM_STRIDE, lane);
+    }
+}
+
+template <typename T, typename TC, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = Cfg<T>::BK;
+    constexpr int KB = Cfg<T>::KB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- tile schedule: XCD-aware (bijective) remap, then groups of 8 row panels ----------
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    const int split = bid / ntiles;
+    bid -= split * ntiles;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int grp = bid / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsize = min(p.tiles_m - first_m, GROUP_M);
+    const int in_grp = bid - grp * per_group;
+    const int tile_m = first_m + in_grp % gsize;
+    const int tile_n = in_grp / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- K range of this split -----------------------------------------------------------
+    const int ksteps_total = (p.K + BK - 1) / BK;
+    const int steps_per = (ksteps_total + p.splitk - 1) / p.splitk;
+    const int ks0 = split * steps_per;
+    const int ks1 = min(ksteps_total, ks0 + steps_per);
+    const int kend = p.K;
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ B = reinterpret_cast<const T*>(p.B);
+
+    // stage s: A image at smem + 2*s*STAGE_BYTES, B image one STAGE_BYTES after it
+#define LDS_A(s) (smem + (s) * 2 * STAGE_BYTES)
+#define LDS_B(s) (smem + (s) * 2 * STAGE_BYTES + STAGE_BYTES)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    if (ks0 < ks1) {
+        stage_load<T, A_KM>(ra, A, p.lda, m0, p.M, ks0 * BK, kend, p.a_vec_ok, tid);
+        stage_load<T, B_KM>(rb, B, p.ldb, n0, p.N, ks0 * BK, kend, p.b_vec_ok, tid);
+        stage_store<T, A_KM>(ra, LDS_A(0), tid);
+        stage_store<T, B_KM>(rb, LDS_B(0), tid);
+    }
+    __syncthreads();
+
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int cur = (ks - ks0) & 1;
+        const bool more = ks + 1 < ks1;
+        if (more) {
+            stage_load<T, A_KM>(ra, A, p.lda, m0, p.M, (ks + 1) * BK, kend, p.a_vec_ok, tid);
+            stage_load<T, B_KM>(rb, B, p.ldb, n0, p.N, (ks + 1) * BK, kend, p.b_vec_ok, tid);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            Frag<T> fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) read_frag<T, A_KM>(fa[i], LDS_A(cur), wm * 64 + i * 16, kb, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) read_frag<T, B_KM>(fb[j], LDS_B(cur), wn * 64 + j * 16, kb, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma(fb[j], fa[i], acc[i][j]);
+        }
+        if (more) {
+            stage_store<T, A_KM>(ra, LDS_A(cur ^ 1), tid);
+            stage_store<T, B_KM>(rb, LDS_B(cur ^ 1), tid);
+        }
+        __syncthreads();
+    }
+
+#undef LDS_A
+#undef LDS_B
+    // ---- epilogue: lane owns C[m][n4 .. n4+3] per (i, j) -----------------------------------
+    const int g = lane >> 4, lm = lane & 15;
+    TC* __restrict__ C = reinterpret_cast<TC*>(p.C);
+    const T* __restrict__ aux_in = reinterpret_cast<const T*>(p.aux_in);
+    T* __restrict__ aux_out = reinterpret_cast<T*>(p.aux_out);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+    const bool atomic = p.splitk > 1;
+    const bool add_bias = p.bias != nullptr && split == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + lm;
+        if (m >= p.M) continue;
+        long orow = m;
+        if (p.grp_rows > 0) orow = (long)(m / p.grp_rows) * p.grp_stride + p.grp_off + m % p.grp_rows;
+        const long rrow = p.res_period > 0 ? (long)(p.res_off + m % p.res_period) : orow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n4 = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n4 >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
+            const bool full = p.c_vec_ok && (n4 + 3 < p.N);
+            if (add_bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n4 + e < p.N) v[e] += p.bias[n4 + e];
+            }
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (aux_out && n4 + e < p.N) aux_out[orow * p.ld_aux + n4 + e] = from_f32<T>(v[e]);
+                    v[e] = gelu_erf(v[e]);
+                }
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == ACT_DGELU || p.act == ACT_DRELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n4 + e < p.N) {
+                        const float h = to_f32<T>(aux_in[orow * p.ld_aux + n4 + e]);
+                        v[e] *= (p.act == ACT_DGELU) ? gelu_erf_grad(h) : (h > 0.f ? 1.f : 0.f);
+                    }
+                }
+            }
+            if (res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n4 + e < p.N) v[e] += to_f32<T>(res[rrow * p.ldr + n4 + e]);
+            }
+            TC* dst = C + orow * p.ldc + n4;
+            if (atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n4 + e < p.N) atomicAdd(reinterpret_cast<float*>(dst) + e, v[e]);
+            } else if (full) {
+                if (sizeof(TC) == 4) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate) {
+                        const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
+                        o += old;
+                    }
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                } else {
+                    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n4 + e < p.N) {
+                        float o = v[e];
+                        if (p.accumulate) o += to_f32<TC>(dst[e]);
+                        dst[e] = from_f32<TC>(o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TC>
+static void launch_gemm(const GemmParams& p, int transA, int transB, hipStream_t stream) {
+    const int grid = p.tiles_m * p.tiles_n * p.splitk;
+    const size_t lds = 4 * STAGE_BYTES;
+    // op(A) is M x K.  transA == 0: A stored [M][K] (K-contiguous); 1: stored [K][M] (K-major).
+    // op(B) is K x N.  transB == 1: B stored [N][K] (K-contiguous); 0: stored [K][N] (K-major).
+    const bool a_km = transA != 0, b_km = transB == 0;
+#define VITK_LAUNCH(AK, BK_)                                                                      \
+    do {                                                                                          \
+        static bool attr_set = false; /* > 64 KiB of dynamic LDS needs an explicit opt-in */      \
+        if (!attr_set) {                                                                          \
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TC, AK, BK_>,                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm_kernel<T, TC, AK, BK_>), dim3(grid), dim3(256), lds, stream, p); \
+    } while (0)
+    if (!a_km && !b_km) VITK_LAUNCH(false, false);
+    else if (!a_km && b_km) VITK_LAUNCH(false, true);
+    else if (a_km && !b_km) VITK_LAUNCH(true, false);
+    else VITK_LAUNCH(true, true);
+#undef VITK_LAUNCH
+}
+
+}  // namespace vitk
+
+using namespace vitk;
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, float alpha,
+                         const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                         const float* bias, int act, const void* aux_in, void* aux_out, long ld_aux,
+                         const void* residual, long ldr, int res_period, int res_off, int grp_rows,
+                         int grp_stride, int grp_off, int accumulate, int splitk, hipStream_t stream) {
+    VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "vitk_gemm: bad dtype %d", dtype);
+    VITK_CHECK_ARG(c_dtype == VITK_F32 || (c_dtype == VITK_BF16 && dtype == VITK_BF16),
+                   "vitk_gemm: unsupported output dtype %d for input dtype %d", c_dtype, dtype);
+    VITK_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "vitk_gemm: negative shape");
+    if (M == 0 || N == 0) return VITK_OK;
+    VITK_CHECK_ARG(A && B && C, "vitk_gemm: null operand");
+    VITK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+                   "vitk_gemm: leading dimension too small (lda %ld ldb %ld ldc %ld)", lda, ldb, ldc);
+    VITK_CHECK_ARG(act >= ACT_NONE && act <= ACT_DRELU, "vitk_gemm: bad act %d", act);
+    VITK_CHECK_ARG(!((act == ACT_DGELU || act == ACT_DRELU) && !aux_in), "vitk_gemm: act %d needs aux_in", act);
+    VITK_CHECK_ARG(!(accumulate && c_dtype != VITK_F32), "vitk_gemm: accumulate needs an fp32 output");
+    VITK_CHECK_ARG(!(residual && res_period < 0), "vitk_gemm: bad res_period");
+    const int esz = dtype == VITK_BF16 ? 2 : 4;
+    const int bk = 128 / esz;
+    const int ksteps = (K + bk - 1) / bk;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    if (splitk <= 0) {  // auto: only when the output is fp32 and there is no nonlinear epilogue
+        splitk = 1;
+        if (c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out && grp_rows == 0) {
+            const int tiles = tiles_m * tiles_n;
+            while (tiles * splitk < 1024 && ksteps / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
+        }
+    }
+    splitk = splitk < 1 ? 1 : (splitk > ksteps ? (ksteps > 0 ? ksteps : 1) : splitk);
+    if (splitk > 1) {
+        VITK_CHECK_ARG(c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out,
+                       "vitk_gemm: split-K needs an fp32 output and a linear epilogue");
+        if (!accumulate) {
+            if (ldc == N && grp_rows == 0) {
+                if (hipMemsetAsync(C, 0, (size_t)M * N * 4, stream) != hipSuccess) {
+                    vitk_set_error("vitk_gemm: memset failed");
+                    return VITK_ERR_LAUNCH;
+                }
+            } else {
+                if (hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream) != hipSuccess) {
+                    vitk_set_error("vitk_gemm: memset2d failed");
+                    return VITK_ERR_LAUNCH;
+                }
+            }
+        }
+    }
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.act = act;
+    p.aux_in = aux_in; p.aux_out = aux_out; p.ld_aux = ld_aux;
+    p.residual = residual; p.ldr = ldr; p.res_period = res_period; p.res_off = res_off;
+    p.grp_rows = grp_rows; p.grp_stride = grp_stride; p.grp_off = grp_off;
+    p.accumulate = accumulate; p.splitk = splitk;
+    p.a_vec_ok = aligned16(A) && (lda * esz) % 16 == 0;
+    p.b_vec_ok = aligned16(B) && (ldb * esz) % 16 == 0;
+    const int csz = c_dtype == VITK_BF16 ? 2 : 4;
+    p.c_vec_ok = (reinterpret_cast<uintptr_t>(C) % (4 * csz) == 0) && (ldc % 4 == 0);
+    p.alpha = alpha;
+    p.tiles_m = tiles_m; p.tiles_n = tiles_n;
+    if (dtype == VITK_BF16) {
+        if (c_dtype == VITK_BF16) launch_gemm<__bf16, __bf16>(p, transA, transB, stream);
+        else launch_gemm<__bf16, float>(p, transA, transB, stream);
+    } else {
+        launch_gemm<float, float>(p, transA, transB, stream);
+    }
+    VITK_CHECK_LAUNCH("vitk_gemm");
+    return VITK_OK;
+}

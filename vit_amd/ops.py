@@ -1,0 +1,211 @@
+"""Thin Python wrappers over the C-ABI (raw pointers + the current HIP stream).
+
+No autograd here and no fallbacks: these take CUDA(HIP) tensors, check layouts on the host
+(a faulting kernel can take the whole box down) and launch.  Autograd lives in functional.py.
+"""
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU, check, lib  # noqa: F401
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f'vit_amd supports float32 / bfloat16 tensors, got {t.dtype}')
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VitkError('vit_amd ops need tensors on the GPU (there is no CPU path)')
+
+
+def _rows2d(t, what):
+    """(ptr, rows, cols, ld) of a 2-D row-major view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1 and t.shape[1] != 1:
+        raise ValueError(f'{what}: need a 2-D tensor with contiguous rows, got {tuple(t.shape)} strides {t.stride()}')
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t.data_ptr(), t.shape[0], t.shape[1], ld
+
+
+def gemm(a, b, *, trans_a=False, trans_b=True, out=None, out_dtype=None, bias=None, act=ACT_NONE,
+         aux_in=None, aux_out=None, residual=None, res_period=0, res_off=0, out_rows=None, grp=None,
+         accumulate=False, splitk=0, alpha=1.0):
+    """out = epilogue(alpha * op(a) @ op(b) + bias) [+ residual].
+
+    op(a) is [M,K]: ``a`` stored [M,K] (trans_a False) or [K,M] (True).
+    op(b) is [K,N]: ``b`` stored [N,K] (trans_b True, the nn.Linear weight layout) or [K,N].
+    grp = (grp_rows, grp_stride, grp_off) remaps output row r to
+    (r // grp_rows) * grp_stride + grp_off + r % grp_rows (patch rows into a token matrix).
+    """
+    _req_cuda(a, b, out, bias, aux_in, aux_out, residual)
+    pa, ra, ca, lda = _rows2d(a, 'gemm a')
+    pb, rb, cb, ldb = _rows2d(b, 'gemm b')
+    M, K = (ca, ra) if trans_a else (ra, ca)
+    N, Kb = (rb, cb) if trans_b else (cb, rb)
+    if K != Kb:
+        raise ValueError(f'gemm: inner dims differ ({K} vs {Kb})')
+    if a.dtype != b.dtype:
+        raise TypeError('gemm: a and b must share a dtype')
+    if out is None:
+        odt = out_dtype or a.dtype
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty(rows, N, device=a.device, dtype=odt)
+    pc, rc, cc, ldc = _rows2d(out, 'gemm out')
+    if cc != N:
+        raise ValueError('gemm: out has the wrong width')
+    grp_rows, grp_stride, grp_off = grp or (0, 0, 0)
+    if grp_rows:
+        last = ((M - 1) // grp_rows) * grp_stride + grp_off + (M - 1) % grp_rows
+        if last >= rc:
+            raise ValueError('gemm: grouped output rows exceed out')
+    elif rc < M:
+        raise ValueError('gemm: out has too few rows')
+    for t, nm in ((aux_in, 'aux_in'), (aux_out, 'aux_out'), (residual, 'residual')):
+        if t is not None and t.dtype != a.dtype:
+            raise TypeError(f'gemm: {nm} must have the input dtype')
+    ld_aux = 0
+    for t in (aux_in, aux_out):
+        if t is not None:
+            _, r_, c_, ld_aux = _rows2d(t, 'gemm aux')
+            if c_ != N or r_ < rc:
+                raise ValueError('gemm: aux shape mismatch')
+    ldr = 0
+    if residual is not None:
+        _, rr, cr, ldr = _rows2d(residual, 'gemm residual')
+        need = (res_off + min(res_period, M)) if res_period else rc
+        if cr != N or rr < need:
+            raise ValueError('gemm: residual shape mismatch')
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError('gemm: bias must be contiguous fp32 [N]')
+    st = lib().vitk_gemm(_dt(a), _dt(out), int(trans_a), int(trans_b), M, N, K, float(alpha),
+                         pa, lda, pb, ldb, pc, ldc, _ptr(bias), act, _ptr(aux_in), _ptr(aux_out), ld_aux,
+                         _ptr(residual), ldr, res_period, res_off, grp_rows, grp_stride, grp_off,
+                         int(accumulate), splitk, _stream())
+    check(st, 'vitk_gemm')
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
+    _req_cuda(x, gamma, beta)
+    px, rows, D, ldx = _rows2d(x, 'layernorm x')
+    y = torch.empty(rows, D, device=x.device, dtype=x.dtype)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if want_stats else None
+    st = lib().vitk_layernorm_fwd(_dt(x), rows, D, px, ldx, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                  y.data_ptr(), D, _ptr(mean), _ptr(rstd), _stream())
+    check(st, 'vitk_layernorm_fwd')
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, add=None):
+    """Returns dx (+ add).  dgamma / dbeta (fp32 [D]) are accumulated into."""
+    _req_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, add)
+    pdy, rows, D, lddy = _rows2d(dy, 'layernorm dy')
+    px, _, _, ldx = _rows2d(x, 'layernorm x')
+    dx = torch.empty(rows, D, device=x.device, dtype=x.dtype)
+    padd, ldadd = 0, 0
+    if add is not None:
+        padd, ra, ca, ldadd = _rows2d(add, 'layernorm add')
+        if (ra, ca) != (rows, D) or add.dtype != x.dtype:
+            raise ValueError('layernorm_bwd: add shape/dtype mismatch')
+    if x.shape != dy.shape or x.dtype != dy.dtype:
+        raise ValueError('layernorm_bwd: x / dy mismatch')
+    st = lib().vitk_layernorm_bwd(_dt(x), rows, D, pdy, lddy, px, ldx, mean.data_ptr(), rstd.data_ptr(),
+                                  gamma.data_ptr(), padd, ldadd, dx.data_ptr(), D, _ptr(dgamma), _ptr(dbeta),
+                                  _stream())
+    check(st, 'vitk_layernorm_bwd')
+    return dx
+
+
+def colsum(x, out=None):
+    """out[n] += sum_m x[m][n] (fp32).  A fresh zeroed ``out`` is made when none is given."""
+    _req_cuda(x, out)
+    px, M, N, ldx = _rows2d(x, 'colsum x')
+    if out is None:
+        out = torch.zeros(N, device=x.device, dtype=torch.float32)
+    st = lib().vitk_colsum(_dt(x), M, N, px, ldx, out.data_ptr(), _stream())
+    check(st, 'vitk_colsum')
+    return out
+
+
+def cast(src, dst):
+    """fp32 -> bf16 or bf16 -> fp32 over flat contiguous buffers."""
+    _req_cuda(src, dst)
+    if not (src.is_contiguous() and dst.is_contiguous()) or src.numel() != dst.numel():
+        raise ValueError('cast: need contiguous buffers of equal length')
+    if src.dtype == torch.float32 and dst.dtype == torch.bfloat16:
+        d = 0
+    elif src.dtype == torch.bfloat16 and dst.dtype == torch.float32:
+        d = 1
+    else:
+        raise TypeError('cast: f32<->bf16 only')
+    check(lib().vitk_cast(d, src.numel(), src.data_ptr(), dst.data_ptr(), _stream()), 'vitk_cast')
+    return dst
+
+
+def patchify(img, P, out_dtype):
+    _req_cuda(img)
+    B, C, H, W = img.shape
+    img = img.contiguous()
+    out = torch.empty(B * (H // P) * (W // P), C * P * P, device=img.device, dtype=out_dtype)
+    check(lib().vitk_patchify(_dt(img), _dt(out), B, C, H, W, P, img.data_ptr(), out.data_ptr(), _stream()),
+          'vitk_patchify')
+    return out
+
+
+def unpatchify(dpatch, B, C, H, W, P):
+    _req_cuda(dpatch)
+    dpatch = dpatch.contiguous()
+    dimg = torch.empty(B, C, H, W, device=dpatch.device, dtype=torch.float32)
+    check(lib().vitk_unpatchify(_dt(dpatch), B, C, H, W, P, dpatch.data_ptr(), dimg.data_ptr(), _stream()),
+          'vitk_unpatchify')
+    return dimg
+
+
+def cls_rows(x, cls, pos):
+    """x [B,N,D] (contiguous): x[:,0] = cls + pos[0]."""
+    B, N, D = x.shape
+    check(lib().vitk_cls_rows(_dt(x), B, N, D, cls.data_ptr(), _ptr(pos), x.data_ptr(), _stream()), 'vitk_cls_rows')
+
+
+def token_grads(dx, dpos, dcls):
+    B, N, D = dx.shape
+    check(lib().vitk_token_grads(_dt(dx), B, N, D, dx.data_ptr(), _ptr(dpos), _ptr(dcls), _stream()),
+          'vitk_token_grads')
+
+
+def attn_fwd(qkv_q, qkv_k, qkv_v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w):
+    """q/k/v: views into [B*N, ld]-strided buffers (element (b,n,h,d) at (b*N+n)*ld + h*dh + d).
+    pk/pq: band tables [2N-1, ld_p] (row r <-> i-j = r-(N-1)) or None.  Returns (out [B*N, H*dh], lse [B,H,N])."""
+    _req_cuda(qkv_q, qkv_k, qkv_v, pk, pq)
+    out = torch.empty(B * N, H * dh, device=qkv_q.device, dtype=qkv_q.dtype)
+    lse = torch.empty(B, H, N, device=qkv_q.device, dtype=torch.float32)
+    st = lib().vitk_attn_fwd(_dt(qkv_q), B, H, N, dh, qkv_q.data_ptr(), qkv_k.data_ptr(), qkv_v.data_ptr(), ld,
+                             _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
+                             out.data_ptr(), H * dh, lse.data_ptr(), _stream())
+    check(st, 'vitk_attn_fwd')
+    return out, lse
+
+
+def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, lse, dq, dk, dv, ld_d, dpk, dpq):
+    """dq/dk/dv: views into a [B*N, ld_d] buffer (same addressing as q/k/v).  dpk/dpq: fp32
+    [2N-1, H*dh], ACCUMULATED into (caller zeroes)."""
+    _req_cuda(q, k, v, pk, pq, out, dout, lse, dq, dk, dv, dpk, dpq)
+    st = lib().vitk_attn_bwd(_dt(q), B, H, N, dh, q.data_ptr(), k.data_ptr(), v.data_ptr(), ld,
+                             _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
+                             out.data_ptr(), dout.data_ptr(), H * dh, lse.data_ptr(),
+                             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d,
+                             _ptr(dpk), _ptr(dpq), H * dh, 0, _stream())
+    check(st, 'vitk_attn_bwd')
