@@ -50,3 +50,45 @@ def test_attn_fwd(dtype, bias, w, B, N, H, dh):
     tol = 1e-5 if dtype == torch.float32 else 1.5e-2
     assert relerr(out.view(B, N, H, dh), ref) < tol
     assert relerr(lse, lse_ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+BWD_CASES = [(2, 65, 4, 32), (1, 197, 3, 64), (1, 197, 2, 80), (2, 16, 2, 64), (1, 300, 2, 64), (3, 130, 2, 128)]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('bias', [False, True], ids=['plain', 'dis'])
+@pytest.mark.parametrize('w', [-1, 8, 20])
+@pytest.mark.parametrize('B,N,H,dh', BWD_CASES)
+def test_attn_bwd(dtype, bias, w, B, N, H, dh):
+    from vit_amd import ops
+    D = H * dh
+    qkv, pk, pq = make(B, N, H, dh, dtype, bias, seed=3 * N + dh)
+    q, k, v = views(qkv, B, N, H, dh)
+    scale = (dh * (3 if bias else 1)) ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, w)
+    g = torch.Generator(device='cuda').manual_seed(7)
+    dout = torch.randn(B * N, D, device='cuda', generator=g).to(dtype)
+    dqkv = torch.full_like(qkv, float('nan'))
+    dq, dk, dv = views(dqkv, B, N, H, dh)
+    dpk = dpq = None
+    if bias:
+        dpk = torch.zeros(2 * N - 1, D, device='cuda')
+        dpq = torch.zeros(2 * N - 1, D, device='cuda')
+    ops.attn_bwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, w, out, dout, lse,
+                 dq, dk, dv, dqkv.stride(0), dpk, dpq)
+    # fp64 autograd of the closed form on the same (rounded) inputs
+    f = lambda t: t.double().reshape(B, N, H, dh).clone().requires_grad_(True)
+    qr, kr, vr = f(q), f(k), f(v)
+    pkr = pqr = None
+    if bias:
+        pkr = pk.double().view(-1, H, dh).clone().requires_grad_(True)
+        pqr = pq.double().view(-1, H, dh).clone().requires_grad_(True)
+    ref, _, _ = attention_ref(qr, kr, vr, pkr, pqr, scale, w)
+    (ref * dout.double().view(B, N, H, dh)).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert relerr(dq.reshape(B, N, H, dh), qr.grad) < tol
+    assert relerr(dk.reshape(B, N, H, dh), kr.grad) < tol
+    assert relerr(dv.reshape(B, N, H, dh), vr.grad) < tol
+    if bias:
+        assert relerr(dpk.view(-1, H, dh), pkr.grad) < tol
+        assert relerr(dpq.view(-1, H, dh), pqr.grad) < tol

@@ -39,7 +39,7 @@ _SIGNATURES = {
                        c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long,
                        c_float, c_int, c_vp, c_vp, c_long, c_vp,
                        c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_vp], c_int),
-    'vitk_favor_features_fwd': None,   # declared when favor.hip lands
+    'vitk_attn_bwd_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),
 }
 
 

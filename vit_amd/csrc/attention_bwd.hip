@@ -1,0 +1,713 @@
+// Fused attention backward: dQ, dK, dV and the gradients of the projected relative tables
+// (dPk, dPq), recomputing the probabilities from Q, K, the tables and the forward's LSE.
+//
+// Replaces the autograd backward of AttentionLAI.forward
+// (timm_classes/timm_locality_aware_transformer.py:51-76) and of
+// Disentangled[LAI]SelfAttention.forward + disentangled_attention_bias
+// (disentangled_transformer/disentangled_transformer.py:324-347, 357-426, 875-919, 929-998):
+// bmm / gather / masked_fill / softmax backward chains over [B*H, N, N] and [B*H, N, 2S] tensors.
+// Here nothing of size N x N (or N x 2S) reaches HBM.
+//
+// With s = scale * raw, raw[i][j] = Q_i.K_j + Q_i.Pk[i-j] + K_j.Pq[i-j], P = softmax(s | band):
+//   delta_i = dO_i . O_i                       dP_ij = dO_i . V_j
+//   dS_ij   = scale * P_ij * (dP_ij - delta_i)                      (= d loss / d raw)
+//   dQ_i = sum_j dS_ij (K_j + Pk[i-j])         dK_j = sum_i dS_ij (Q_i + Pq[i-j])
+//   dV_j = sum_i P_ij dO_i
+//   dPk[r] = sum_{b, i-j=r} dS_ij Q_i          dPq[r] = sum_{b, i-j=r} dS_ij K_j
+//
+// Three kernels:
+//   attn_delta_kernel : delta[b][h][i]  (HBM-bound row dot)
+//   attn_bwd_kernel   : key-stationary.  A workgroup owns 64*KTW keys of one (b, h) (a wave owns
+//                       16*KTW of them: K/V fragments and the dK^T/dV^T accumulators stay in
+//                       registers) and sweeps the queries in blocks of 32.  Scores are computed
+//                       with the KEY on the MFMA lane, so P and dS tiles are directly the B
+//                       operands of dV^T += dO^T P and dK^T += Q^T dS.  dS crosses LDS once
+//                       (per-wave scratch) for dQ and for the Toeplitz (relative-position) terms,
+//                       which are MFMA products against skewed reads of that scratch:
+//                         dK^T[d][jj] += sum_t Pq^T[d][t] Sy[t][jj],  Sy[t][jj] = dS[jj+t-15][jj]
+//                         dQ^T[d][ii] += sum_t Pk^T[d][t] Sx[t][ii],  Sx[t][ii] = dS[ii][ii+15-t]
+//                       dQ is reduced over the 4 waves in LDS, then added to an fp32 accumulator
+//                       in HBM (one 256-byte row segment per wave instruction).
+//   attn_bwd_rel_kernel: dPk / dPq.  A wave owns one 16x16-tile DIAGONAL of one head and walks
+//                       it for a whole group of batches: along a diagonal the 31 relative rows a
+//                       tile touches never change, so the table fragments and the dPk/dPq
+//                       accumulators stay in registers and are flushed once (fp32 atomics, tiny).
+#include "attn_common.h"
+
+namespace vitk {
+
+constexpr int DSLD = 20;  // floats per row of a 16x16 dS scratch tile (16-byte aligned rows)
+
+struct AttnBwdParams {
+    const void *q, *k, *v;
+    long ld;
+    const void *pk, *pq;
+    long ld_p;
+    const void* out;
+    const void* dout;
+    long ldo;
+    const float* lse;   // [B][H][N]
+    float* delta;       // [B][H][N] workspace
+    float* dq_acc;      // fp32 accumulator, element (b, n, h, d) at (b*N + n) * ld_acc + h*dh + d
+    long ld_acc;
+    void *dk, *dv;      // T, element at (b*N + n) * ld_d + h*dh + d
+    long ld_d;
+    float *dpk, *dpq;   // fp32 [2N-1][ld_dp] (+ h*dh + d), accumulated into
+    long ld_dp;
+    int B, H, N, dh;
+    float scale;
+    int w;
+    int bgroup;         // rel kernel: batches per wave
+};
+
+__device__ __forceinline__ void frag_set(Frag<__bf16>& f, int e, float v) { f.v[e] = (__bf16)v; }
+__device__ __forceinline__ void frag_set(Frag<float>& f, int e, float v) { f.v[e] = v; }
+
+// ------------------------------------------------------------------ delta = rowsum(dO * O)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ out, const T* __restrict__ dout,
+                                                         long ldo, float* __restrict__ delta, int B, int H, int N,
+                                                         int dh) {
+    constexpr int EPC = 16 / sizeof(T);
+    const long total = (long)B * N * H;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int h = idx % H;
+        const long bn = idx / H;
+        const int n = bn % N;
+        const int b = bn / N;
+        const T* o = out + bn * ldo + h * dh;
+        const T* d = dout + bn * ldo + h * dh;
+        float s = 0.f;
+        for (int c = 0; c < dh; c += EPC) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(o + c);
+            const u32x4 g = *reinterpret_cast<const u32x4*>(d + c);
+            const T* ae = reinterpret_cast<const T*>(&a);
+            const T* ge = reinterpret_cast<const T*>(&g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s += (float)ae[e] * (float)ge[e];
+        }
+        delta[((long)b * H + h) * N + n] = s;
+    }
+}
+
+// Skewed fragments of a 16x16 dS tile held in LDS as ds[ii][jj] (row stride DSLD floats).
+//   Sx : element e <- dS[li][li + 15 - (8g+e)]     (B operand, k = t = 8g+e, column ii = li)
+//   Sy : element e <- dS[li + (8g+e) - 15][li]     (B operand, k = t = 8g+e, column jj = li)
+template <typename T>
+__device__ __forceinline__ void skew_x(Frag<T>& f, const float* ds, int g, int li) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int jj = li + 15 - 8 * g - e;
+        const float v = ds[li * DSLD + min(max(jj, 0), 15)];
+        frag_set(f, e, (jj >= 0 && jj < 16) ? v : 0.f);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void skew_y(Frag<T>& f, const float* ds, int g, int li) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ii = li + 8 * g + e - 15;
+        const float v = ds[min(max(ii, 0), 15) * DSLD + li];
+        frag_set(f, e, (ii >= 0 && ii < 16) ? v : 0.f);
+    }
+}
+
+template <typename T, int DKB, int KTW, int NW, bool BIAS> struct BwdCfg {
+    using C = ACfg<T, DKB>;
+    static constexpr int NT = 64 * NW;                // threads per workgroup
+    static constexpr int KB = 16 * KTW * NW;          // keys per workgroup
+    static constexpr int WIN = KB + 32;               // staged relative rows (KB + 31 used)
+    static constexpr int DQLD = 32 * DKB + 4;         // floats per row of the dQ reduction tile
+    static constexpr int WSCR = (BIAS ? 2 * SCR_FLOATS : 0) + KTW * 16 * DSLD;  // floats per wave
+    static constexpr size_t lds_bytes() {
+        return (size_t)(64 + KB + (BIAS ? 2 * WIN : 0)) * C::ASTR * sizeof(T) +
+               (size_t)(64 + 32 * DQLD + NW * WSCR) * sizeof(float);
+    }
+};
+
+template <typename T, int DKB, int KTW, int NW, bool BIAS>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p) {
+    using C = ACfg<T, DKB>;
+    using BC = BwdCfg<T, DKB, KTW, NW, BIAS>;
+    constexpr int NTH = BC::NT;
+    constexpr int ASTR = C::ASTR;
+    constexpr int KB = BC::KB, WIN = BC::WIN, DQLD = BC::DQLD;
+    constexpr int ND = 2 * DKB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Qs = reinterpret_cast<T*>(smem);
+    T* dOs = Qs + 32 * ASTR;
+    T* Ks = dOs + 32 * ASTR;
+    T* Pks = Ks + KB * ASTR;
+    T* Pqs = Pks + (BIAS ? WIN * ASTR : 0);
+    float* lse2s = reinterpret_cast<float*>(Pqs + (BIAS ? WIN * ASTR : 0));
+    float* dls = lse2s + 32;
+    float* dQs = dls + 32;
+    float* scr = dQs + 32 * DQLD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int N = p.N, dh = p.dh, H = p.H;
+    const int kb0 = blockIdx.x * KB, h = blockIdx.y, b = blockIdx.z;
+    const int kw0 = 16 * KTW * wave;   // wave's first key inside the block
+    const int jw = kb0 + kw0;
+
+    float* xs = scr + wave * BC::WSCR;
+    float* ys = xs + (BIAS ? SCR_FLOATS : 0);
+    float* dss = ys + (BIAS ? SCR_FLOATS : 0);
+
+    const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
+    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
+    const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + (long)b * N * p.ldo + h * dh;
+    const T* PK = BIAS ? reinterpret_cast<const T*>(p.pk) + h * dh : nullptr;
+    const T* PQ = BIAS ? reinterpret_cast<const T*>(p.pq) + h * dh : nullptr;
+    const float* lse = p.lse + ((long)b * H + h) * N;
+    const float* delta = p.delta + ((long)b * H + h) * N;
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+
+    int ilo = 0, ihi = N;
+    if (p.w >= 0) {
+        ilo = max(0, kb0 - p.w);
+        ihi = min(N, kb0 + KB + p.w);
+        ilo = (ilo / 32) * 32;
+    }
+
+    stage_rows<T, DKB>(Ks, K, p.ld, kb0, KB, 0, N, dh, tid, NTH);
+    __syncthreads();
+
+    Frag<T> kf[KTW][DKB], vf[KTW][DKB];
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) {
+            row_frag<T, DKB>(kf[kt][kb], Ks, kw0 + 16 * kt, kb, lane);
+            row_frag_global<T>(vf[kt][kb], V, p.ld, jw + 16 * kt + li, N, dh, kb, lane);
+        }
+    f32x4 dkacc[KTW][ND], dvacc[KTW][ND];
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            dkacc[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dvacc[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    for (int i0 = ilo; i0 < ihi; i0 += 32) {
+        __syncthreads();
+        stage_rows<T, DKB>(Qs, Q, p.ld, i0, 32, 0, N, dh, tid, NTH);
+        stage_rows<T, DKB>(dOs, dO, p.ldo, i0, 32, 0, N, dh, tid, NTH);
+        if (BIAS) {
+            const int r_lo = i0 - kb0 - KB + 1 + (N - 1);  // table row of window row 0
+            stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WIN, 0, 2 * N - 1, dh, tid, NTH);
+            stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WIN, 0, 2 * N - 1, dh, tid, NTH);
+        }
+        if (tid < 32) {
+            const int qi = i0 + tid;
+            lse2s[tid] = qi < N ? lse[qi] * LOG2E : 0.f;
+            dls[tid] = qi < N ? delta[qi] : 0.f;
+        }
+        for (int i = tid; i < 32 * DQLD; i += NTH) dQs[i] = 0.f;
+        __syncthreads();
+
+        const bool wave_live =
+            jw < N && (p.w < 0 || !(jw > i0 + 31 + p.w || jw + 16 * KTW - 1 < i0 - p.w));
+        if (wave_live) {
+            f32x4 pt[2][KTW], dst[2][KTW];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int qi0 = i0 + 16 * qt;
+                Frag<T> qf[DKB], dof[DKB];
+#pragma unroll
+                for (int kb = 0; kb < DKB; ++kb) {
+                    row_frag<T, DKB>(qf[kb], Qs, 16 * qt, kb, lane);
+                    row_frag<T, DKB>(dof[kb], dOs, 16 * qt, kb, lane);
+                }
+                f32x4 dqa[ND];
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) dqa[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt) {
+                    const int kj0 = jw + 16 * kt;
+                    float* ds = dss + kt * 16 * DSLD;
+                    const bool dead = kj0 >= N || qi0 >= N ||
+                                      (p.w >= 0 && (kj0 > qi0 + 15 + p.w || kj0 + 15 < qi0 - p.w));
+                    const int rel = 16 * qt - (kw0 + 16 * kt) + KB - 16;
+                    f32x4 pv = {0.f, 0.f, 0.f, 0.f}, dsv = {0.f, 0.f, 0.f, 0.f};
+                    if (!dead) {
+                        const f32x4 raw = score_tile<T, DKB, BIAS, false>(qf, kf[kt], Pks, Pqs, rel, xs, ys, lane);
+                        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < DKB; ++kb) dp = mma(dof[kb], vf[kt][kb], dp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int qr = 16 * qt + 4 * g + r;
+                            const int qi = i0 + qr, kj = kj0 + li;
+                            const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
+                            const float pe = ok ? exp2f(raw[r] * sc2 - lse2s[qr]) : 0.f;
+                            pv[r] = pe;
+                            dsv[r] = pe * (dp[r] - dls[qr]) * p.scale;
+                        }
+                    }
+                    pt[qt][kt] = pv;
+                    dst[qt][kt] = dsv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[(4 * g + r) * DSLD + li] = dsv[r];
+                    wave_lds_sync();
+                    if (BIAS && !dead) {
+                        Frag<T> sx, sy;
+                        skew_x<T>(sx, ds, g, li);
+                        skew_y<T>(sy, ds, g, li);
+#pragma unroll
+                        for (int dt = 0; dt < ND; ++dt) {
+                            Frag<T> a;
+                            col_frag(a, Pks, ASTR, rel + 8 * g, rel + 8 * g + 4, 16 * dt, lane);
+                            dqa[dt] = mma(a, sx, dqa[dt]);
+                            col_frag(a, Pqs, ASTR, rel + 8 * g, rel + 8 * g + 4, 16 * dt, lane);
+                            dkacc[kt][dt] = mma(a, sy, dkacc[kt][dt]);
+                        }
+                    }
+                }
+                // content part of dQ^T[d][ii] += sum_key K^T[d][key] dS^T[key][ii]
+                {
+                    Frag<T> bs;
+                    const int kt_of_g = (KTW == 2) ? (g >> 1) : 0;
+                    const float* ds = dss + kt_of_g * 16 * DSLD + li * DSLD + 8 * (g & 1);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(ds);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(ds + 4);
+                    const bool use = (KTW == 2) || g < 2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        frag_set(bs, e, use ? lo[e] : 0.f);
+                        frag_set(bs, 4 + e, use ? hi[e] : 0.f);
+                    }
+                    const int krow = kw0 + ((KTW == 2) ? 8 * g : 8 * (g & 1));
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) {
+                        Frag<T> a;
+                        col_frag(a, Ks, ASTR, krow, krow + 4, 16 * dt, lane);
+                        dqa[dt] = mma(a, bs, dqa[dt]);
+                    }
+                }
+                // dqa[dt][r] = dQ^T[d = 16dt+4g+r][ii = li]: reduce over the workgroup's waves in LDS
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        atomicAdd(&dQs[(16 * qt + li) * DQLD + 16 * dt + 4 * g + r], dqa[dt][r]);
+                wave_lds_sync();
+            }
+            // content parts of dV^T[d][key] += dO^T[d][q] P[q][key], dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+                Frag<T> bp, bs;
+                acc_to_frag(bp, pt[0][kt], pt[1][kt]);
+                acc_to_frag(bs, dst[0][kt], dst[1][kt]);
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    Frag<T> a;
+                    col_frag(a, dOs, ASTR, 4 * g, 16 + 4 * g, 16 * dt, lane);
+                    dvacc[kt][dt] = mma(a, bp, dvacc[kt][dt]);
+                    col_frag(a, Qs, ASTR, 4 * g, 16 + 4 * g, 16 * dt, lane);
+                    dkacc[kt][dt] = mma(a, bs, dkacc[kt][dt]);
+                }
+            }
+        }
+        __syncthreads();
+        // dQ block -> fp32 accumulator in HBM (a wave instruction covers contiguous d of one row)
+        for (int idx = tid; idx < 32 * dh; idx += NTH) {
+            const int r = idx / dh, d = idx - r * dh;
+            const int qi = i0 + r;
+            if (qi < N) {
+                const float v = dQs[r * DQLD + d];
+                atomicAdd(p.dq_acc + ((long)b * N + qi) * p.ld_acc + h * dh + d, v);
+            }
+        }
+    }
+
+    // dK / dV of the wave's keys: acc[dt][r] = X^T[d = 16dt+4g+r][key = li]
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) {
+        const int kj = jw + 16 * kt + li;
+        if (kj < N) {
+            T* dK = reinterpret_cast<T*>(p.dk) + ((long)b * N + kj) * p.ld_d + h * dh;
+            T* dV = reinterpret_cast<T*>(p.dv) + ((long)b * N + kj) * p.ld_d + h * dh;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const int d = 16 * dt + 4 * g;
+                if (d < dh) {
+                    if (sizeof(T) == 2) {
+                        const f32x4 a = dkacc[kt][dt], c = dvacc[kt][dt];
+                        *reinterpret_cast<bf16x4*>(dK + d) = bf16x4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+                        *reinterpret_cast<bf16x4*>(dV + d) = bf16x4{(__bf16)c[0], (__bf16)c[1], (__bf16)c[2], (__bf16)c[3]};
+                    } else {
+                        *reinterpret_cast<f32x4*>(dK + d) = dkacc[kt][dt];
+                        *reinterpret_cast<f32x4*>(dV + d) = dvacc[kt][dt];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ dPk / dPq
+// Raw score tile with the relative-table fragments already in registers (the 32 table rows of
+// a tile diagonal): same math as score_tile<.., BIAS = true, TRANS = false>.
+template <typename T, int DKB>
+__device__ __forceinline__ f32x4 score_tile_diag(const Frag<T> (&qf)[DKB], const Frag<T> (&kf)[DKB],
+                                                 const Frag<T> (&pkf)[2][DKB], const Frag<T> (&pqf)[2][DKB],
+                                                 float* xs, float* ys, int lane) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < DKB; ++kb) s = mma(qf[kb], kf[kb], s);
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) {
+            x = mma(pkf[u][kb], qf[kb], x);
+            y = mma(pqf[u][kb], kf[kb], y);
+        }
+        *reinterpret_cast<f32x4*>(xs + li * SCR_LD + 16 * u + 4 * g) = x;
+        *reinterpret_cast<f32x4*>(ys + li * SCR_LD + 16 * u + 4 * g) = y;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ii = 4 * g + r, jj = li;
+        const int t = ii - jj + 15;
+        s[r] += xs[ii * SCR_LD + t] + ys[jj * SCR_LD + t];
+    }
+    wave_lds_sync();
+    return s;
+}
+
+template <typename T, int DKB> struct RelCfg {
+    using C = ACfg<T, DKB>;
+    // per wave: Q pair + K pair images (32 rows each), xs, ys, two dS tiles
+    static constexpr size_t wave_bytes() {
+        return (size_t)64 * C::ASTR * sizeof(T) + (size_t)(2 * SCR_FLOATS + 2 * 16 * DSLD) * sizeof(float);
+    }
+};
+
+template <typename T, int DKB>
+__global__ __launch_bounds__(256) void attn_bwd_rel_kernel(const AttnBwdParams p) {
+    using C = ACfg<T, DKB>;
+    constexpr int ASTR = C::ASTR;
+    constexpr int ND = 2 * DKB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    char* wbase = smem + wave * RelCfg<T, DKB>::wave_bytes();
+    T* Qw = reinterpret_cast<T*>(wbase);
+    T* Kw = Qw + 32 * ASTR;
+    float* xs = reinterpret_cast<float*>(Kw + 32 * ASTR);
+    float* ys = xs + SCR_FLOATS;
+    float* dss = ys + SCR_FLOATS;
+
+    const int N = p.N, dh = p.dh, H = p.H;
+    const int NT = (N + 15) / 16;
+    const int cw = blockIdx.x * 4 + wave;   // wrapped tile diagonal
+    const int h = blockIdx.y;
+    const int b_lo = blockIdx.z * p.bgroup, b_hi = min(p.B, b_lo + p.bgroup);
+    if (cw >= NT) return;   // whole wave leaves; no workgroup barriers below
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
+    const T* PQ = reinterpret_cast<const T*>(p.pq) + h * dh;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = pass == 0 ? cw : cw - NT;
+        if (pass == 1 && cw == 0) break;
+        const int ac = c < 0 ? -c : c;
+        if (p.w >= 0 && 16 * ac - 15 > p.w) continue;   // whole diagonal outside the LAI band
+        const int ntile = NT - ac;
+        const int ibase = 16 * (c > 0 ? c : 0), jbase = 16 * (c < 0 ? -c : 0);
+        const int R0 = 16 * c - 15 + (N - 1);            // table row of t = 0
+
+        Frag<T> pkf[2][DKB], pqf[2][DKB];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int kb = 0; kb < DKB; ++kb) {
+                const int row = R0 + 16 * u + li;
+                const int d = 32 * kb + 8 * g;
+                if (row >= 0 && row < 2 * N - 1 && d < dh) {
+                    frag_load(pkf[u][kb], PK + (long)row * p.ld_p + d);
+                    frag_load(pqf[u][kb], PQ + (long)row * p.ld_p + d);
+                } else {
+                    frag_zero(pkf[u][kb]);
+                    frag_zero(pqf[u][kb]);
+                }
+            }
+        f32x4 apk[2][ND], apq[2][ND];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                apk[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                apq[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+
+        for (int b = b_lo; b < b_hi; ++b) {
+            const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
+            const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
+            const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
+            const T* dO = reinterpret_cast<const T*>(p.dout) + (long)b * N * p.ldo + h * dh;
+            const float* lse = p.lse + ((long)b * H + h) * N;
+            const float* delta = p.delta + ((long)b * H + h) * N;
+            for (int m = 0; m < ntile; m += 2) {
+                const int i0 = ibase + 16 * m, j0 = jbase + 16 * m;
+                // stage the pair's 32 query rows and 32 key rows (rows past the diagonal's last
+                // tile are zero-filled so they contribute nothing)
+                const int ilim = min(N, ibase + 16 * ntile), jlim = min(N, jbase + 16 * ntile);
+                stage_rows<T, DKB>(Qw, Q, p.ld, i0, 32, 0, ilim, dh, lane, 64);
+                stage_rows<T, DKB>(Kw, K, p.ld, j0, 32, 0, jlim, dh, lane, 64);
+                wave_lds_sync();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qi0 = i0 + 16 * u, kj0 = j0 + 16 * u;
+                    float* ds = dss + u * 16 * DSLD;
+                    f32x4 dsv = {0.f, 0.f, 0.f, 0.f};
+                    if (m + u < ntile) {
+                        Frag<T> qf[DKB], kf[DKB], vf[DKB], dof[DKB];
+#pragma unroll
+                        for (int kb = 0; kb < DKB; ++kb) {
+                            row_frag<T, DKB>(qf[kb], Qw, 16 * u, kb, lane);
+                            row_frag<T, DKB>(kf[kb], Kw, 16 * u, kb, lane);
+                            row_frag_global<T>(vf[kb], V, p.ld, kj0 + li, N, dh, kb, lane);
+                            row_frag_global<T>(dof[kb], dO, p.ldo, qi0 + li, N, dh, kb, lane);
+                        }
+                        const f32x4 raw = score_tile_diag<T, DKB>(qf, kf, pkf, pqf, xs, ys, lane);
+                        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < DKB; ++kb) dp = mma(dof[kb], vf[kb], dp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int qi = qi0 + 4 * g + r, kj = kj0 + li;
+                            const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
+                            const int qc = min(qi, N - 1);
+                            const float pe = ok ? exp2f(raw[r] * sc2 - lse[qc] * LOG2E) : 0.f;
+                            dsv[r] = pe * (dp[r] - delta[qc]) * p.scale;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[(4 * g + r) * DSLD + li] = dsv[r];
+                }
+                wave_lds_sync();
+                // dPk[t][d] += sum_ii Sx[t][ii] Q[ii][d],  dPq[t][d] += sum_jj Sy[t][jj] K[jj][d]
+                // K dimension = the pair's 32 rows: k = 8g+e -> tile (g >> 1), local row 8(g&1)+e
+                {
+                    const float* ds = dss + (g >> 1) * 16 * DSLD;
+                    const int lbase = 8 * (g & 1);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int t = li + 16 * u;
+                        Frag<T> ax, ay;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int l = lbase + e;
+                            const int jj = l + 15 - t;   // Sx[t][ii = l] = dS[l][l + 15 - t]
+                            const float vx = ds[l * DSLD + min(max(jj, 0), 15)];
+                            frag_set(ax, e, (jj >= 0 && jj < 16) ? vx : 0.f);
+                            const int ii = l + t - 15;   // Sy[t][jj = l] = dS[l + t - 15][l]
+                            const float vy = ds[min(max(ii, 0), 15) * DSLD + l];
+                            frag_set(ay, e, (ii >= 0 && ii < 16) ? vy : 0.f);
+                        }
+#pragma unroll
+                        for (int dt = 0; dt < ND; ++dt) {
+                            Frag<T> bq, bk;
+                            col_frag(bq, Qw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
+                            col_frag(bk, Kw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
+                            apk[u][dt] = mma(ax, bq, apk[u][dt]);
+                            apq[u][dt] = mma(ay, bk, apq[u][dt]);
+                        }
+                    }
+                }
+                wave_lds_sync();
+            }
+        }
+        // flush: acc[u][dt][r] = dP*[t = 16u+4g+r][d = 16dt+li]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * u + 4 * g + r;
+                const int row = R0 + t;
+                if (t < 31 && row >= 0 && row < 2 * N - 1) {
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) {
+                        const int d = 16 * dt + li;
+                        if (d < dh) {
+                            atomicAdd(p.dpk + (long)row * p.ld_dp + h * dh + d, apk[u][dt][r]);
+                            atomicAdd(p.dpq + (long)row * p.ld_dp + h * dh + d, apq[u][dt][r]);
+                        }
+                    }
+                }
+            }
+    }
+}
+
+// fp32 accumulator rows -> T rows (bf16 path's dQ)
+__global__ void cast_rows_kernel(const float* __restrict__ src, long lds_, __bf16* __restrict__ dst, long ldd, long rows,
+                                 int cols) {
+    const int c4 = cols >> 2;
+    const long total = rows * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * lds_ + c);
+        *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+}
+
+template <typename T, int DKB, int KTW, int NW, bool BIAS>
+static void bwd_launch(const AttnBwdParams& p, hipStream_t st) {
+    using BC = BwdCfg<T, DKB, KTW, NW, BIAS>;
+    static_assert(BC::lds_bytes() <= 160 * 1024, "attention backward tile does not fit the LDS");
+    const size_t lds = BC::lds_bytes();
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, DKB, KTW, NW, BIAS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid((p.N + BC::KB - 1) / BC::KB, p.H, p.B);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, DKB, KTW, NW, BIAS>), grid, dim3(BC::NT), lds, st, p);
+}
+
+template <typename T, int DKB> static void rel_launch(const AttnBwdParams& p, int zgroups, hipStream_t st) {
+    const size_t lds = 4 * RelCfg<T, DKB>::wave_bytes();
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_rel_kernel<T, DKB>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int NT = (p.N + 15) / 16;
+    dim3 grid((NT + 3) / 4, p.H, zgroups);
+    hipLaunchKernelGGL((attn_bwd_rel_kernel<T, DKB>), grid, dim3(256), lds, st, p);
+}
+
+template <typename T, int KTW> static void bwd_dispatch(const AttnBwdParams& p, int zgroups, hipStream_t st) {
+    const int dkb = (p.dh + 31) / 32;
+    const bool bias = p.pk != nullptr;
+    // fp32 tiles of wide heads (and dh > 96 in bf16) only fit the LDS with a 2-wave workgroup
+#define VITK_CASE(D)                                                               \
+    case D: {                                                                      \
+        constexpr int NW = ((sizeof(T) == 4 && D >= 3) || D >= 4) ? 2 : 4;         \
+        if (bias) {                                                                \
+            bwd_launch<T, D, KTW, NW, true>(p, st);                                \
+            rel_launch<T, D>(p, zgroups, st);                                      \
+        } else {                                                                   \
+            bwd_launch<T, D, KTW, NW, false>(p, st);                               \
+        }                                                                          \
+    } break;
+    switch (dkb) {
+        VITK_CASE(1)
+        VITK_CASE(2)
+        VITK_CASE(3)
+        VITK_CASE(4)
+    }
+#undef VITK_CASE
+}
+
+}  // namespace vitk
+
+using namespace vitk;
+
+static bool b16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Bytes of fp32 workspace vitk_attn_bwd needs: delta [B*H*N] (+ the dQ accumulator for bf16).
+extern "C" long vitk_attn_bwd_workspace_bytes(int dtype, int B, int H, int N, int dh) {
+    long n = ((long)B * H * N + 63) / 64 * 64;
+    if (dtype == VITK_BF16) n += (long)B * N * H * dh;
+    return n * 4;
+}
+
+extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void* q, const void* k, const void* v,
+                             long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
+                             const void* out, const void* dout, long ldo, const float* lse, void* dq, void* dk,
+                             void* dv, long ld_d, float* dpk, float* dpq, long ld_dp, void* workspace,
+                             hipStream_t stream) {
+    VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "vitk_attn_bwd: bad dtype");
+    VITK_CHECK_ARG(B > 0 && H > 0 && N > 0, "vitk_attn_bwd: empty problem");
+    const int esz = dtype == VITK_BF16 ? 2 : 4;
+    VITK_CHECK_ARG(dh > 0 && dh <= 128 && (dh * esz) % 16 == 0, "vitk_attn_bwd: head dim %d unsupported", dh);
+    VITK_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && workspace, "vitk_attn_bwd: null pointer");
+    VITK_CHECK_ARG((pk == nullptr) == (pq == nullptr), "vitk_attn_bwd: pk and pq go together");
+    VITK_CHECK_ARG(!pk || (dpk && dpq), "vitk_attn_bwd: dpk/dpq required with pk/pq");
+    const long HD = (long)H * dh;
+    VITK_CHECK_ARG(b16(q) && b16(k) && b16(v) && b16(out) && b16(dout) && b16(dq) && b16(dk) && b16(dv) &&
+                       (ld * esz) % 16 == 0 && (ldo * esz) % 16 == 0 && (ld_d * esz) % 16 == 0 && ld >= HD &&
+                       ldo >= HD && ld_d >= HD,
+                   "vitk_attn_bwd: rows must be 16-byte aligned and at least H*dh wide");
+    VITK_CHECK_ARG(!pk || (b16(pk) && b16(pq) && (ld_p * esz) % 16 == 0 && ld_p >= HD && ld_dp >= HD),
+                   "vitk_attn_bwd: band tables must be 16-byte aligned rows of at least H*dh");
+    VITK_CHECK_ARG(b16(workspace), "vitk_attn_bwd: workspace must be 16-byte aligned");
+    VITK_CHECK_ARG(H <= 65535 && B <= 65535, "vitk_attn_bwd: grid too large");
+
+    AttnBwdParams p;
+    p.q = q; p.k = k; p.v = v; p.ld = ld;
+    p.pk = pk; p.pq = pq; p.ld_p = ld_p;
+    p.out = out; p.dout = dout; p.ldo = ldo;
+    p.lse = lse;
+    p.delta = reinterpret_cast<float*>(workspace);
+    p.dk = dk; p.dv = dv; p.ld_d = ld_d;
+    p.dpk = dpk; p.dpq = dpq; p.ld_dp = ld_dp;
+    p.B = B; p.H = H; p.N = N; p.dh = dh;
+    p.scale = scale; p.w = band_w;
+    // batches per wave in the table-gradient kernel: enough waves to fill the chip, few flushes
+    const int NT = (N + 15) / 16;
+    int live_diags = NT;
+    if (band_w >= 0) live_diags = 1 + 2 * ((band_w + 15) / 16);
+    if (live_diags > NT) live_diags = NT;
+    int zgroups = (2048 + live_diags * H - 1) / (live_diags * H);
+    if (zgroups > B) zgroups = B;
+    if (zgroups < 1) zgroups = 1;
+    p.bgroup = (B + zgroups - 1) / zgroups;
+    zgroups = (B + p.bgroup - 1) / p.bgroup;
+
+    const long rows = (long)B * N;
+    float* delta_end = p.delta + ((long)B * H * N + 63) / 64 * 64;
+    if (dtype == VITK_BF16) {
+        p.dq_acc = delta_end;
+        p.ld_acc = HD;
+        if (hipMemsetAsync(p.dq_acc, 0, (size_t)rows * HD * 4, stream) != hipSuccess) {
+            vitk_set_error("vitk_attn_bwd: memset failed");
+            return VITK_ERR_LAUNCH;
+        }
+    } else {
+        p.dq_acc = reinterpret_cast<float*>(dq);
+        p.ld_acc = ld_d;
+        if (hipMemset2DAsync(dq, (size_t)ld_d * 4, 0, (size_t)HD * 4, (size_t)rows, stream) != hipSuccess) {
+            vitk_set_error("vitk_attn_bwd: memset2d failed");
+            return VITK_ERR_LAUNCH;
+        }
+    }
+    {
+        const long total = rows * H;
+        long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (dtype == VITK_BF16)
+            hipLaunchKernelGGL(attn_delta_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, stream, (const __bf16*)out,
+                               (const __bf16*)dout, ldo, p.delta, B, H, N, dh);
+        else
+            hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((int)blocks), dim3(256), 0, stream, (const float*)out,
+                               (const float*)dout, ldo, p.delta, B, H, N, dh);
+    }
+    if (dtype == VITK_BF16) {
+        bwd_dispatch<__bf16, 2>(p, zgroups, stream);
+        long blocks = (rows * (HD / 4) + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(cast_rows_kernel, dim3((int)blocks), dim3(256), 0, stream, p.dq_acc, HD, (__bf16*)dq, ld_d,
+                           rows, (int)HD);
+    } else {
+        bwd_dispatch<float, 1>(p, zgroups, stream);
+    }
+    VITK_CHECK_LAUNCH("vitk_attn_bwd");
+    return VITK_OK;
+}

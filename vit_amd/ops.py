@@ -199,13 +199,22 @@ def attn_fwd(qkv_q, qkv_k, qkv_v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w):
     return out, lse
 
 
-def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, lse, dq, dk, dv, ld_d, dpk, dpq):
+def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, lse, dq, dk, dv, ld_d, dpk, dpq,
+             workspace=None):
     """dq/dk/dv: views into a [B*N, ld_d] buffer (same addressing as q/k/v).  dpk/dpq: fp32
-    [2N-1, H*dh], ACCUMULATED into (caller zeroes)."""
-    _req_cuda(q, k, v, pk, pq, out, dout, lse, dq, dk, dv, dpk, dpq)
+    [2N-1, H*dh], ACCUMULATED into (caller zeroes).  ``workspace``: optional uint8 scratch of at
+    least attn_bwd_workspace_bytes(...) (allocated when not given)."""
+    _req_cuda(q, k, v, pk, pq, out, dout, lse, dq, dk, dv, dpk, dpq, workspace)
+    need = lib().vitk_attn_bwd_workspace_bytes(_dt(q), B, H, N, dh)
+    if workspace is None:
+        workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError('attn_bwd: workspace too small')
+    if not (out.is_contiguous() and dout.is_contiguous()) or out.shape != (B * N, H * dh) or dout.shape != out.shape:
+        raise ValueError('attn_bwd: out / dout must be contiguous [B*N, H*dh]')
     st = lib().vitk_attn_bwd(_dt(q), B, H, N, dh, q.data_ptr(), k.data_ptr(), v.data_ptr(), ld,
                              _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
                              out.data_ptr(), dout.data_ptr(), H * dh, lse.data_ptr(),
                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d,
-                             _ptr(dpk), _ptr(dpq), H * dh, 0, _stream())
+                             _ptr(dpk), _ptr(dpq), H * dh, workspace.data_ptr(), _stream())
     check(st, 'vitk_attn_bwd')
