@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: synthetic-image TRAINING throughput of the ViT encoder hot path.
+
+  python bench.py --gpus N --steps K --warmup W         (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = forward + label-smoothing CE + backward (+ bucketed RCCL gradient all-reduce when
+N > 1, overlapped with backward) + AdamW, on one per-GPU batch of synthetic images
+(train.py:530-554 of the reference).  Default workload: ViT-B/16-224 LAI + disentangled
+(BASELINE.json's metric config: 24 layers x 1024 x 4096 x 16 heads, 197 tokens, per-GPU batch 128,
+bf16 compute / fp32 master weights, LAI stage w = 20).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     : the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs per launch / HIP-event
+                 time per launch, summed over every GEMM launch of the timed steps, vs 2.5 PF.
+  cpu_baseline : the CPU oracle (oracle/ref_cpu.py, the reference's algorithm in plain fp32
+                 PyTorch) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name: (attention variant, preset, img, patch, classes, default per-GPU batch)
+    'dislai_b16': ('disentangled_lai_attention', 'B', 224, 16, 1000, 128),
+    'dis_b16': ('disentangled_attention', 'B', 224, 16, 1000, 128),
+    'lai_s16': ('transformer_timm_lai', 'S', 224, 16, 1000, 128),
+    'dislai_l16': ('disentangled_lai_attention', 'L', 224, 16, 1000, 64),
+    'regular_cifar': ('transformer', 'cifar', 32, 4, 10, 128),
+}
+MASK_EPOCHS = [10, 20, 30, 40]
+STAGE_EPOCH = {8: 0, 12: 10, 18: 20, 20: 30, -1: 40}
+
+
+def train_flops_per_image(variant, p, N, P, C, B, w):
+    """Algorithmic FLOPs of one training step per image = 3 x forward; flash
+    recompute and LN / GELU / softmax are not counted."""
+    D, F, L, H = p['dim'], p['mlp'], p['depth'], p['heads']
+    fwd = 2.0 * (N - 1) * 3 * P * P * D + 2.0 * D * C
+    wbar = N if w < 0 else (N * (2 * w + 1) - w * (w + 1)) / N
+    lin = 8.0 * N * D * D + 4.0 * N * D * F
+    if variant.startswith('disentangled'):
+        attn = 8.0 * N * wbar * D
+        table = 4.0 * (2 * N - 1) * D * D / B
+    else:
+        attn = 4.0 * N * wbar * D
+        table = 0.0
+    fwd += L * (lin + attn + table)
+    return 3.0 * fwd
+
+
+def cpu_baseline(args, variant, preset, img, patch, classes, w):
+    """Oracle (port of the reference algorithm) on host cores, bounded sample."""
+    from oracle import ref_cpu as R
+    from vit_amd.train import PRESETS
+    p = PRESETS[preset]
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    me = MASK_EPOCHS if 'lai' in variant else None
+    depth = min(p['depth'], args.cpu_layers)
+    torch.manual_seed(0)
+    if variant == 'transformer_timm_lai':
+        net = R.RefVisionTransformerLAI(img_size=img, patch_size=patch, num_classes=classes, embed_dim=p['dim'],
+                                        depth=depth, num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'],
+                                        mask_epochs=me)
+    elif variant == 'transformer':
+        tr = R.RefTransformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+                              num_encoder_layers=depth, normalize_before=True)
+        net = R.RefVisionTransformer(img_size=img, patch_size=patch, num_classes=classes, transformer=tr)
+    else:
+        tr = R.RefDisentangledTransformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+                                          num_encoder_layers=depth, normalize_before=True, pos_att_type='c2p|p2c',
+                                          max_position_embeddings=p['dim'], relative_attention=True,
+                                          lai='lai' in variant, mask_epochs=me)
+        net = R.RefVisionTransformer(img_size=img, patch_size=patch, num_classes=classes, transformer=tr)
+    opt = torch.optim.AdamW([q for q in net.parameters()], lr=1e-4)
+    Bc = args.cpu_batch
+    x = torch.randn(Bc, 3, img, img)
+    y = torch.randint(0, classes, (Bc,))
+    epoch = STAGE_EPOCH[w] if me is not None else None
+    R.train_step(net, opt, x, y, epoch)           # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < args.cpu_steps:
+        R.train_step(net, opt, x, y, epoch)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    # the sample runs `depth` of the model's layers; scale the per-image time to the full depth
+    # with the measured per-layer cost (layers are identical; embed/head are < 1 % of the step)
+    scale = p['depth'] / depth
+    return {'value': Bc / (dt * scale), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/ref_cpu.py fp32, batch {Bc}, {depth} of {p["depth"]} layers timed over {n} step(s) '
+                      f'(fwd+bwd+AdamW), per-image time scaled x{scale:g} to full depth'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='dislai_b16', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (0 = workload default)')
+    ap.add_argument('--band', type=int, default=20, help='LAI half width stage: 8, 12, 18, 20 or -1 (unmasked)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--bucket-mb', type=int, default=128)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=4)
+    ap.add_argument('--cpu-steps', type=int, default=1)
+    ap.add_argument('--cpu-layers', type=int, default=24)
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from vit_amd import ops
+    from vit_amd.train import PRESETS, build_model, train_step, takes_epoch
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    variant, preset, img, patch, classes, dbatch = WORKLOADS[args.workload]
+    B = args.batch or dbatch
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    p = PRESETS[preset]
+    N = (img // patch) ** 2 + 1
+
+    torch.manual_seed(0)       # identical init on every rank (rank 0 is broadcast anyway)
+    net = build_model(variant, preset, img_size=img, patch_size=patch, num_classes=classes,
+                      mask_epochs=MASK_EPOCHS if 'lai' in variant else None, dtype=dtype, device=dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, fused=True)
+    reducer = None
+    if world > 1:
+        from vit_amd.ddp import GradReducer
+        reducer = GradReducer(net, bucket_mb=args.bucket_mb)
+    epoch = STAGE_EPOCH[args.band] if takes_epoch(net) else None
+    w = args.band if ('lai' in variant and epoch is not None) else -1
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(B, 3, img, img, device=dev, generator=g)
+    y = torch.randint(0, classes, (B,), device=dev, generator=g)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = train_step(net, opt, x, y, epoch, reducer=reducer)
+    timer = None if args.no_kernel_timer else []
+    ops.KERNEL_TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(net, opt, x, y, epoch, reducer=reducer)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_val = float(loss)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    fl_img = train_flops_per_image(variant, p, N, patch, classes, B, w)
+    model_tflops_gpu = fl_img * B * args.steps / elapsed / 1e12
+
+    roofline = None
+    if timer:
+        agg = {}
+        for name, fl, e0, e1 in timer:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        dom = max(agg, key=lambda k: agg[k][1])
+        fl, sec, cnt = agg[dom]
+        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': fl / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': fl / sec / 1e12 / peak, 'traffic': None, 'launches': cnt,
+                    'avg_launch_us': 1e6 * sec / cnt, 'avg_gflop_per_launch': fl / cnt / 1e9,
+                    'share_of_step_time': sec / elapsed,
+                    'all_gemm_tflops': sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12,
+                    'all_gemm_share_of_step_time': sum(v[1] for v in agg.values()) / elapsed}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, variant, preset, img, patch, classes, w)
+        out = {
+            'metric': 'train images/sec (node) ViT-B/16-224 LAI+Dis' if args.workload == 'dislai_b16'
+                      else f'train images/sec (node) {args.workload}',
+            'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: {variant} preset {preset} ({p["depth"]}L x {p["dim"]} x '
+                                   f'{p["mlp"]} x {p["heads"]}h), {img}x{img}/{patch}, {N} tokens, LAI w={w}, '
+                                   f'dropout 0, AdamW lr 1e-4, label smoothing 0.1',
+                       'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'grad_bucket_mb': args.bucket_mb if world > 1 else None},
+            'train_gflop_per_image': fl_img / 1e9, 'model_tflops_per_gpu': model_tflops_gpu,
+            'mfma_roofline_frac_per_gpu': model_tflops_gpu / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16
+                                                                else PEAK_F32_TFLOPS),
+            'loss': loss_val, 'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

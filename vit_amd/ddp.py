@@ -1,0 +1,132 @@
+"""Data-parallel gradient exchange: the replacement for the reference's
+``torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])`` (train.py:635,
+utils/ops.py:124-133) on one 8 x MI355X node: one process per GPU, RCCL over xGMI
+(torch.distributed backend "nccl" on ROCm; "gloo" for CPU rehearsals).
+
+Design (MI355X first, not a DDP translation):
+  * gradients LIVE in a few large flat fp32 slabs: every used parameter's ``.grad`` is a view
+    into its bucket, so backward writes land in the slab and no copy-in / copy-out pass exists;
+  * buckets follow REVERSE registration order (the order backward produces gradients) and are
+    sized for xGMI: 7 point-to-point links x ~153 GB/s per GPU make a ring all-reduce per-link
+    bound, so few, large (default 128 MiB) collectives amortise latency while still leaving
+    ~10 buckets per step to overlap with the remaining backward;
+  * a bucket's all-reduce is issued from the post-accumulate hook of its LAST parameter, on
+    RCCL's own stream (async_op), overlapping the rest of backward; ``finish()`` makes the
+    compute stream wait for all of them and applies 1/world;
+  * parameters that never receive a gradient (23 in the disentangled models: pos_embed, out.*,
+    pos_key/query_proj, the layer-level q/k/v_proj -- SURVEY.md section 7) are found on the first
+    step and left with ``grad = None`` so AdamW skips them exactly as in the reference; stock DDP
+    would raise on them.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, module, bucket_mb=128, process_group=None, broadcast=True):
+        if not dist.is_initialized():
+            raise RuntimeError('GradReducer needs torch.distributed to be initialised')
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.bucket_bytes = int(bucket_mb * 1024 * 1024)
+        self.built = False
+        self.buckets = []        # flat fp32 tensors
+        self._pending = []       # per bucket: parameters still missing this step
+        self._bucket_of = {}
+        self._handles = []
+        self._hooks = []
+        self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == 'nccl' else dist.ReduceOp.SUM
+        if broadcast and self.world > 1:
+            self.broadcast_parameters(module)
+
+    def broadcast_parameters(self, module):
+        """Rank 0's weights and buffers to every rank (what DDP's constructor does), one flat
+        broadcast per dtype instead of one per tensor."""
+        with torch.no_grad():
+            tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+            by_type = {}
+            for t in tensors:
+                by_type.setdefault((t.dtype, t.device), []).append(t)
+            for ts in by_type.values():
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                dist.broadcast(flat, 0, group=self.group)
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+
+    # ---------------------------------------------------------------- bucket construction
+    def _build(self):
+        used = [p for p in self.params if p.grad is not None]
+        order = list(reversed(used))
+        groups, cur, cur_bytes = [], [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > self.bucket_bytes:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for bi, ps in enumerate(groups):
+            n = sum((p.numel() + 63) // 64 * 64 for p in ps)    # 256-byte aligned views
+            flat = torch.zeros(n, device=ps[0].device, dtype=torch.float32)
+            off = 0
+            for p in ps:
+                view = flat[off:off + p.numel()].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
+                self._bucket_of[p] = bi
+                off += (p.numel() + 63) // 64 * 64
+            self.buckets.append(flat)
+        self._groups = groups
+        for p in used:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.built = True
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[p]
+        pend = self._pending[bi]
+        pend.discard(p)
+        if not pend and self._launched is not None and not self._launched[bi]:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        self._launched[bi] = True
+        if self.world > 1:
+            self._handles.append(dist.all_reduce(self.buckets[bi], op=self._avg, group=self.group, async_op=True))
+
+    # ---------------------------------------------------------------- per-step protocol
+    def prepare(self):
+        """Call instead of optimizer.zero_grad(), before backward."""
+        self._handles = []
+        if not self.built:
+            for p in self.params:
+                p.grad = None
+            self._launched = None
+            return
+        for flat in self.buckets:
+            flat.zero_()
+        self._pending = [set(ps) for ps in self._groups]
+        self._launched = [False] * len(self.buckets)
+
+    def finish(self):
+        """Call after backward, before optimizer.step()."""
+        if not self.built:
+            self._build()
+            self._pending = [set() for _ in self.buckets]
+            self._launched = [False] * len(self.buckets)
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:       # a parameter got no gradient this step: reduce zeros for it
+                self._launch(bi)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if self.world > 1 and self._avg != dist.ReduceOp.AVG:
+            for flat in self.buckets:
+                flat.mul_(1.0 / self.world)
+
+    def bytes_per_step(self):
+        return sum(b.numel() * 4 for b in self.buckets)

@@ -1,0 +1,282 @@
+"""MI355X drop-ins for the reference's DeBERTa-style disentangled encoder.
+
+Class names, constructor / forward signatures and state_dict keys follow
+``disentangled_transformer/disentangled_transformer.py`` in the reference
+(DisentangledTransformer :15, DisentangledEncoder :75, DisentangledEncoderLayer :130,
+DisentangledSelfAttention :248, DisentangledLAISelfAttention :788).  Parameters the reference
+allocates but never uses (pos_key_proj / pos_query_proj, the layer-level query/key/value_proj)
+are kept so checkpoints load; they receive no gradient here either.
+
+What runs: with delta = i - j,
+    score[b,h,i,j] = (Q_i.K_j + Q_i.Pk[delta] + K_j.Pq[delta]) / sqrt(3 dh)
+where Pk / Pq are the LayerNormed relative table projected with the CONTENT key / query
+projections (share_att_key = True, reference :270,373-377).  Only the 2N-1 reachable rows of the
+table are projected; the kernels index them by delta, so neither relative_pos nor any
+[B*H, N, 2S] tensor exists.  The LAI variant adds the band predicate |i-j| <= w in-kernel.
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import functional as VF
+from ..precision import ComputeDtypeMixin
+from ..timm_classes.timm_locality_aware_transformer import _check_p0, get_attn_mask, lai_stage_width  # noqa: F401
+
+_band_idx_cache = {}
+
+
+def band_rows(rel_embeddings, N, span):
+    """Rows of the (LayerNormed) relative table reachable at sequence length N, ordered by
+    delta = -(N-1) .. N-1: row r <-> clamp(delta + span, 0, 2 span - 1)
+    (reference :392,405 with build_relative_position, utils/ops.py:61-70)."""
+    key = (N, span, rel_embeddings.device)
+    idx = _band_idx_cache.get(key)
+    if idx is None:
+        idx = (torch.arange(-(N - 1), N, device=rel_embeddings.device) + span).clamp_(0, 2 * span - 1)
+        _band_idx_cache[key] = idx
+    return rel_embeddings.index_select(0, idx)
+
+
+class DisentangledSelfAttention(ComputeDtypeMixin, nn.Module):
+    _lai = False
+
+    def __init__(self, d_model=512, nhead=8, dropout=0.1, relative_attention=True, pos_att_type='c2p|p2c',
+                 position_buckets=-1, max_relative_positions=-1, max_position_embeddings=512):
+        super().__init__()
+        self.num_attention_heads = nhead
+        self.attention_head_size = int(d_model / nhead)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.pos_att_type = [x.strip() for x in pos_att_type.lower().split('|')]
+        self.relative_attention = relative_attention
+        self.share_att_key = True
+        self.query_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.key_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.value_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        if self.relative_attention:
+            if position_buckets > 0:
+                raise NotImplementedError('log-bucketed relative positions are dead code in the reference '
+                                          '(position_buckets = -1 at every call site) and are not built')
+            if sorted(t for t in self.pos_att_type if t) != ['c2p', 'p2c']:
+                raise NotImplementedError("only pos_att_type 'c2p|p2c' (the reference's CLI default) is built")
+            self.position_buckets = position_buckets
+            self.max_relative_positions = max_relative_positions
+            if self.max_relative_positions < 1:
+                self.max_relative_positions = max_position_embeddings
+            self.pos_ebd_size = self.max_relative_positions
+            self.pos_dropout = nn.Dropout(dropout)
+            self.pos_key_proj = nn.Linear(d_model, self.all_head_size, bias=True)   # unused, as in the reference
+            self.pos_query_proj = nn.Linear(d_model, self.all_head_size)            # unused, as in the reference
+        self.dropout = nn.Dropout(dropout)
+        self.mask_epochs = None
+
+    def scale(self):
+        terms = 1 + (2 if self.relative_attention else 0)
+        return 1.0 / math.sqrt(self.attention_head_size * terms)
+
+    def band_for(self, rel_embeddings, N, dtype):
+        if not self.relative_attention:
+            return None
+        if rel_embeddings is None:
+            raise ValueError('relative attention needs rel_embeddings')
+        return band_rows(rel_embeddings, N, self.pos_ebd_size).to(dtype)
+
+    def _width(self, epoch):
+        return lai_stage_width(epoch, self.mask_epochs) if self._lai else None
+
+    def forward(self, q, k, value, relative_pos=None, rel_embeddings=None, query=None, pos_embed=None, epoch=0):
+        """Returns {'hidden_states': [B,N,D], 'attention_probs': None, 'attention_logits': None}.
+        The probabilities / logits the reference also returns are discarded by its only caller
+        (reference :222) and are never materialised here.  ``relative_pos`` must be the default
+        i - j grid (it is regenerated from indices in-kernel)."""
+        _check_p0(self, self.dropout.p, self.pos_dropout.p if self.relative_attention else 0.)
+        if relative_pos is not None and relative_pos.dim() not in (2, 3, 4):
+            raise ValueError(f'Relative postion ids must be of dim 2 or 3 or 4. {relative_pos.dim()}')
+        if query is not None:
+            q = query
+        B, N, D = q.shape
+        if k.shape != q.shape or value.shape != q.shape:
+            raise NotImplementedError('cross attention (different q / k lengths) is not on the reference hot path')
+        dt = self.compute_dtype
+        H = self.num_attention_heads
+        band = self.band_for(rel_embeddings, N, dt)
+        w = self._width(epoch)
+        qp, kp, vp = self.query_proj, self.key_proj, self.value_proj
+        if q is k and k is value:
+            x2 = q.reshape(B * N, D).to(dt)
+            ctx = VF.DisAttentionFn.apply(x2, band, qp.weight, qp.bias, kp.weight, kp.bias, vp.weight, vp.bias,
+                                          (B, N, H, self.scale(), w))
+        else:
+            r2 = lambda t: t.reshape(B * N, D).to(dt)
+            qkv = torch.cat([VF.linear(r2(q), qp.weight, qp.bias), VF.linear(r2(k), kp.weight, kp.bias),
+                             VF.linear(r2(value), vp.weight, vp.bias)], dim=1)
+            tables = None
+            if band is not None:
+                tables = torch.cat([VF.linear(band, qp.weight, qp.bias), VF.linear(band, kp.weight, kp.bias)], dim=1)
+            ctx = VF.attention(qkv, tables, B, N, H, D // H, self.scale(), w)
+        return {'hidden_states': ctx.view(B, N, D).to(q.dtype), 'attention_probs': None, 'attention_logits': None}
+
+
+class DisentangledLAISelfAttention(DisentangledSelfAttention):
+    _lai = True
+
+    def __init__(self, d_model=512, nhead=8, dropout=0.1, relative_attention=True, pos_att_type='c2p|p2c',
+                 position_buckets=-1, max_relative_positions=-1, max_position_embeddings=512, mask_epochs=None):
+        super().__init__(d_model, nhead, dropout, relative_attention, pos_att_type, position_buckets,
+                         max_relative_positions, max_position_embeddings)
+        self.mask_epochs = mask_epochs
+
+
+class DisentangledSelfAttentionPerformer(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('DisentangledSelfAttentionPerformer (reference :431-785) is marked unfinished '
+                                  'upstream and is outside this build (SURVEY.md 8f, item 1)')
+
+
+class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
+    def __init__(self, d_model=512, nhead=8, dropout=0.1, relative_attention=True, pos_att_type='c2p|p2c',
+                 position_buckets=-1, max_relative_positions=-1, max_position_embeddings=512, dim_feedforward=2048,
+                 performers=False, lai=False, mask_epochs=None, norf=32, kernel='softmax'):
+        super().__init__()
+        kw = dict(d_model=d_model, nhead=nhead, dropout=dropout, relative_attention=relative_attention,
+                  pos_att_type=pos_att_type, position_buckets=position_buckets,
+                  max_relative_positions=max_relative_positions, max_position_embeddings=max_position_embeddings)
+        if performers:
+            self.dis_attn = DisentangledSelfAttentionPerformer(kernel=kernel, norf=norf, **kw)
+        elif lai:
+            self.dis_attn = DisentangledLAISelfAttention(mask_epochs=mask_epochs, **kw)
+        else:
+            self.dis_attn = DisentangledSelfAttention(**kw)
+        self.embed_size = d_model
+        self.num_attention_heads = nhead
+        self.attention_head_size = int(d_model / nhead)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        # allocated and never used by the reference (:168-170, :207-210); kept for state_dict parity
+        self.query_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.key_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.value_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.dense_AttnOut = nn.Linear(d_model, d_model)
+        self.layer_norm_AttnOut = nn.LayerNorm(d_model)
+        self.dropout_AttnOut = nn.Dropout(dropout)
+        self.dense_intermediate = nn.Linear(d_model, dim_feedforward)
+        self.act_intermediate = nn.GELU()
+        self.dense_out = nn.Linear(dim_feedforward, d_model)
+        self.layer_norm_out = nn.LayerNorm(d_model)
+        self.dropout_out = nn.Dropout(dropout)
+
+    def forward2d(self, x2, band, B, N, epoch):
+        """x2 [B*N, D] and band [2N-1, D] (or None) in compute dtype -> [B*N, D]; one autograd node."""
+        a = self.dis_attn
+        _check_p0(self, a.dropout.p, self.dropout_AttnOut.p, self.dropout_out.p)
+        if self.layer_norm_AttnOut.eps != self.layer_norm_out.eps:
+            raise NotImplementedError('DisentangledEncoderLayer: the two LayerNorms must share eps')
+        cfg = (B, N, a.num_attention_heads, self.layer_norm_out.eps, a.scale(), a._width(0 if epoch is None else epoch),
+               'gelu')
+        q, k, v = a.query_proj, a.key_proj, a.value_proj
+        return VF.DisLayerFn.apply(x2, band, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
+                                   self.dense_AttnOut.weight, self.dense_AttnOut.bias,
+                                   self.layer_norm_AttnOut.weight, self.layer_norm_AttnOut.bias,
+                                   self.dense_intermediate.weight, self.dense_intermediate.bias,
+                                   self.dense_out.weight, self.dense_out.bias,
+                                   self.layer_norm_out.weight, self.layer_norm_out.bias, cfg)
+
+    def forward(self, src, relative_pos=None, rel_embeddings=None, query=None, pos_embed=None, epoch=None):
+        if query is not None:
+            raise NotImplementedError('query != src is not on the reference hot path')
+        B, N, D = src.shape
+        dt = self.compute_dtype
+        band = self.dis_attn.band_for(rel_embeddings, N, dt)
+        y = self.forward2d(src.reshape(B * N, D).to(dt), band, B, N, epoch)
+        return y.view(B, N, D).to(src.dtype)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class DisentangledEncoder(ComputeDtypeMixin, nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None, relative_attention=True, max_relative_positions=-1,
+                 position_buckets=-1, performers=False):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        d_model = encoder_layer.embed_size
+        max_position_embeddings = d_model   # as the reference (:87)
+        self.relative_attention = relative_attention
+        if self.relative_attention:
+            self.max_relative_positions = max_relative_positions
+            if self.max_relative_positions < 1:
+                self.max_relative_positions = max_position_embeddings
+            self.position_buckets = position_buckets
+            pos_ebd_size = self.max_relative_positions * 2
+            if self.position_buckets > 0:
+                pos_ebd_size = self.position_buckets * 2
+            self.rel_embeddings = nn.Embedding(pos_ebd_size, d_model)
+            self.LayerNorm = nn.LayerNorm(d_model)
+
+    def get_rel_embedding(self):
+        """LayerNorm of the whole relative table, once per forward, shared by every layer
+        (reference :102-106); runs on the fp32 LayerNorm kernel."""
+        if not self.relative_attention:
+            return None
+        return VF.layer_norm(self.rel_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+    def encode2d(self, x2, B, N, epoch):
+        """Layers only (no final norm) on a 2-D token matrix in compute dtype."""
+        rel = self.get_rel_embedding()
+        dt = self.compute_dtype
+        band = None
+        for layer in self.layers:
+            if band is None:
+                band = layer.dis_attn.band_for(rel, N, dt)   # identical for every (cloned) layer
+            x2 = layer.forward2d(x2, band, B, N, epoch)
+        return x2
+
+    def forward(self, src, pos=None, epoch=None):
+        B, N, D = src.shape
+        dt = self.compute_dtype
+        x2 = self.encode2d(src.reshape(B * N, D).to(dt), B, N, epoch)
+        if self.norm is not None:
+            x2 = VF.layer_norm(x2, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x2.view(B, N, D).to(src.dtype)
+
+
+class DisentangledTransformer(ComputeDtypeMixin, nn.Module):
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, dropout=0.1,
+                 activation="relu", normalize_before=False, return_intermediate_dec=False, pos_att_type='c2p|p2c',
+                 relative_attention=False, position_buckets=-1, max_relative_positions=-1,
+                 max_position_embeddings=512, performers=False, norf=32, kernel='softmax', lai=False,
+                 mask_epochs=None):
+        super().__init__()
+        encoder_layer = DisentangledEncoderLayer(
+            d_model=d_model, nhead=nhead, dropout=dropout, dim_feedforward=dim_feedforward,
+            relative_attention=relative_attention, pos_att_type=pos_att_type, position_buckets=position_buckets,
+            max_relative_positions=max_relative_positions, max_position_embeddings=max_position_embeddings,
+            performers=performers, lai=lai, mask_epochs=mask_epochs, norf=norf, kernel=kernel)
+        encoder_norm = nn.LayerNorm(d_model) if normalize_before else None
+        self.encoder = DisentangledEncoder(encoder_layer, num_encoder_layers, encoder_norm, performers=performers)
+        self._reset_parameters()
+        self.d_model = d_model
+        self.nhead = nhead
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    # protocol used by vit_amd.model.VisionTransformer's fused path
+    def encode2d(self, x2, B, N, epoch):
+        return self.encoder.encode2d(x2, B, N, epoch)
+
+    @property
+    def final_norm(self):
+        return self.encoder.norm
+
+    def forward(self, src, pos_embed, epoch=None):
+        """[B,N,D] -> [N,B,D]; ``pos_embed`` is accepted and, as in the reference (:121 commented
+        out), never added."""
+        memory = self.encoder(src, pos=None, epoch=epoch)
+        return memory.permute(1, 0, 2)

@@ -1,0 +1,420 @@
+"""Autograd layer over the C-ABI kernels: one ``torch.autograd.Function`` per fused unit.
+
+Each Function runs a hand-scheduled forward and backward made of ``ops.*`` launches (HIP kernels
+through libvitk.so); torch supplies only tensors, the stream and the autograd graph edges.  There
+is no fallback path: every op here needs GPU tensors.
+
+Numerics policy: parameters stay fp32 (the reference is fp32-only).  ``dtype`` selects the compute
+type: fp32 runs the exact f32 MFMA path (parity to 1e-5), bf16 keeps a bf16 shadow of each weight
+(refreshed when the parameter's version counter moves) and bf16 activations with fp32
+accumulation, statistics, softmax, bias, LayerNorm affine and all parameter gradients.
+"""
+import weakref
+
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU
+
+_shadow = {}
+
+
+def shadow(params, dtype):
+    """Compute-dtype copy of one parameter, or of the row-concatenation of several (fused QKV)."""
+    if isinstance(params, torch.Tensor):
+        params = (params,)
+    if len(params) == 1 and params[0].dtype == dtype:
+        return params[0].detach()
+    key = tuple(id(p) for p in params) + (dtype,)
+    ver = tuple((p._version, p.data_ptr()) for p in params)
+    hit = _shadow.get(key)
+    if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
+        return hit[1]
+    with torch.no_grad():
+        src = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], 0)
+        if dtype == torch.bfloat16 and src.dtype == torch.float32:
+            src = src.contiguous()
+            dst = torch.empty(src.shape, device=src.device, dtype=dtype)
+            ops.cast(src.view(-1), dst.view(-1))
+        else:
+            dst = src.to(dtype)
+    if len(_shadow) > 4096:
+        for k in [k for k, v in _shadow.items() if any(r() is None for r in v[2])]:
+            del _shadow[k]
+    _shadow[key] = (ver, dst, tuple(weakref.ref(p) for p in params))
+    return dst
+
+
+def _f32(t):
+    return None if t is None else t.detach()
+
+
+def _act_codes(act):
+    """(forward epilogue, backward epilogue, backward aux is the pre-activation?)"""
+    if act == 'gelu':
+        return ACT_GELU, ACT_DGELU
+    if act == 'relu':
+        return ACT_RELU, ACT_DRELU
+    raise ValueError(f'unsupported activation {act!r}')
+
+
+def _dw(dy, x):
+    """dW[out, in] = dy^T x in fp32 (split-K over the token dimension)."""
+    return ops.gemm(dy, x, trans_a=True, trans_b=False, out_dtype=torch.float32)
+
+
+def _dx(dy, w, **kw):
+    return ops.gemm(dy, w, trans_b=False, **kw)
+
+
+# --------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x) over the last dim of a 2-D row view (rows may be strided)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = ops.layernorm_fwd(x, _f32(gamma), _f32(beta), eps)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        D = x.shape[1]
+        dg = torch.zeros(D, device=x.device, dtype=torch.float32)
+        db = torch.zeros(D, device=x.device, dtype=torch.float32)
+        dx = ops.layernorm_bwd(dy if dy.stride(1) == 1 else dy.contiguous(), x, mean, rstd, _f32(gamma), dg, db)
+        return dx, dg, db, None
+
+
+def layer_norm(x2d, gamma, beta, eps):
+    return LayerNormFn.apply(x2d, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------- Linear
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on 2-D rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_dtype):
+        w = shadow(weight, x.dtype)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.gemm(x, w, bias=_f32(bias), out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.to(x.dtype).contiguous()
+        w = shadow(weight, x.dtype)
+        dx = _dx(dy, w) if ctx.needs_input_grad[0] else None
+        dw = _dw(dy, x)
+        db = ops.colsum(dy) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+def linear(x2d, weight, bias=None, out_dtype=None):
+    return LinearFn.apply(x2d, weight, bias, out_dtype)
+
+
+# --------------------------------------------------------------------------- attention core
+def _attn_fwd(qkv, B, N, H, dh, tables, scale, w):
+    """qkv [B*N, 3D] (q | k | v).  tables: None or [2N-1, 2D] (Pq | Pk)."""
+    D = H * dh
+    ld = qkv.stride(0)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    pq = pk = None
+    ld_p = 0
+    if tables is not None:
+        pq, pk = tables[:, :D], tables[:, D:]
+        ld_p = tables.stride(0)
+    return ops.attn_fwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w)
+
+
+def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse):
+    """Returns dqkv [B*N, 3D] and (for tables) fp32 dtables [2N-1, 2D] (dPq | dPk)."""
+    D = H * dh
+    ld = qkv.stride(0)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    dqkv = torch.empty(B * N, 3 * D, device=qkv.device, dtype=qkv.dtype)
+    dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+    pq = pk = dpq = dpk = dtab = None
+    ld_p = 0
+    if tables is not None:
+        pq, pk = tables[:, :D], tables[:, D:]
+        ld_p = tables.stride(0)
+        dtab = torch.zeros(2 * N - 1, 2 * D, device=qkv.device, dtype=torch.float32)
+        dpq, dpk = dtab[:, :D], dtab[:, D:]
+    ops.attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w, out, dout, lse,
+                 dq, dk, dv, 3 * D, dpk, dpq, ld_dp=2 * D)
+    return dqkv, dtab
+
+
+class AttentionFn(torch.autograd.Function):
+    """Fused attention on a packed qkv buffer: softmax(scale * (QK^T [+ c2p + p2c]) | LAI band) V."""
+
+    @staticmethod
+    def forward(ctx, qkv, tables, B, N, H, dh, scale, w):
+        out, lse = _attn_fwd(qkv, B, N, H, dh, tables, scale, w)
+        ctx.save_for_backward(qkv, tables, out, lse)
+        ctx.cfg = (B, N, H, dh, scale, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, tables, out, lse = ctx.saved_tensors
+        B, N, H, dh, scale, w = ctx.cfg
+        dqkv, dtab = _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout.contiguous(), lse)
+        if dtab is not None:
+            dtab = dtab.to(tables.dtype)
+        return dqkv, dtab, None, None, None, None, None, None
+
+
+def attention(qkv, tables, B, N, H, dh, scale, w):
+    return AttentionFn.apply(qkv, tables, B, N, H, dh, scale, w)
+
+
+# --------------------------------------------------------------------------- fused encoder blocks
+def _mlp_fwd(x, w1, b1, w2, b2, act, residual):
+    """y = act(x W1^T + b1) W2^T + b2 + residual.  Returns y, hmid, pre (pre is None for relu)."""
+    fwd_code, _ = _act_codes(act)
+    pre = torch.empty(x.shape[0], w1.shape[0], device=x.device, dtype=x.dtype) if act == 'gelu' else None
+    hmid = ops.gemm(x, w1, bias=b1, act=fwd_code, aux_out=pre)
+    y = ops.gemm(hmid, w2, bias=b2, residual=residual)
+    return y, hmid, pre
+
+
+def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad):
+    """Returns dx (+ residual_grad), dW1, db1, dW2, db2."""
+    _, bwd_code = _act_codes(act)
+    db2 = ops.colsum(dy)
+    dw2 = _dw(dy, hmid)
+    dpre = _dx(dy, w2, act=bwd_code, aux_in=pre if act == 'gelu' else hmid)
+    db1 = ops.colsum(dpre)
+    dw1 = _dw(dpre, x)
+    dx = _dx(dpre, w1, residual=residual_grad)
+    return dx, dw1, db1, dw2, db2
+
+
+class PreLNBlockFn(torch.autograd.Function):
+    """x + proj(attn(LN1(x))) then + mlp(LN2(.)) -- BlockLAI.forward
+    (timm_classes/timm_locality_aware_transformer.py:96-99) and, with act='relu' and no band,
+    TransformerEncoderLayer.forward_pre (model.py:194-204)."""
+
+    @staticmethod
+    def forward(ctx, x, g1, be1, wqkv, bqkv, wproj, bproj, g2, be2, w1, b1, w2, b2, cfg):
+        B, N, H, eps, scale, w, act = cfg
+        D = x.shape[1]
+        dh = D // H
+        dt = x.dtype
+        h1, mean1, rstd1 = ops.layernorm_fwd(x, _f32(g1), _f32(be1), eps)
+        qkv = ops.gemm(h1, shadow(wqkv, dt), bias=_f32(bqkv))
+        attn, lse = _attn_fwd(qkv, B, N, H, dh, None, scale, w)
+        x1 = ops.gemm(attn, shadow(wproj, dt), bias=_f32(bproj), residual=x)
+        h2, mean2, rstd2 = ops.layernorm_fwd(x1, _f32(g2), _f32(be2), eps)
+        y, hmid, pre = _mlp_fwd(h2, shadow(w1, dt), _f32(b1), shadow(w2, dt), _f32(b2), act, x1)
+        ctx.save_for_backward(x, g1, wqkv, wproj, g2, w1, w2, mean1, rstd1, h1, qkv, attn, lse, x1, mean2, rstd2,
+                              h2, hmid, pre)
+        ctx.cfg = cfg
+        ctx.has_qkv_bias = bqkv is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, g1, wqkv, wproj, g2, w1, w2, mean1, rstd1, h1, qkv, attn, lse, x1, mean2, rstd2, h2, hmid,
+         pre) = ctx.saved_tensors
+        B, N, H, eps, scale, w, act = ctx.cfg
+        D = x.shape[1]
+        dh = D // H
+        dt = x.dtype
+        dy = dy.contiguous()
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dh2, dw1, db1, dw2, db2 = _mlp_bwd(dy, h2, shadow(w1, dt), shadow(w2, dt), act, hmid, pre, None)
+        dg2, dbe2 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy)
+        dbproj = ops.colsum(dx1)
+        dwproj = _dw(dx1, attn)
+        dattn = _dx(dx1, shadow(wproj, dt))
+        dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse)
+        dbqkv = ops.colsum(dqkv) if ctx.has_qkv_bias else None
+        dwqkv = _dw(dqkv, h1)
+        dh1 = _dx(dqkv, shadow(wqkv, dt))
+        dg1, dbe1 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        dx = ops.layernorm_bwd(dh1, x, mean1, rstd1, _f32(g1), dg1, dbe1, add=dx1)
+        return dx, dg1, dbe1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbe2, dw1, db1, dw2, db2, None
+
+
+class DisLayerFn(torch.autograd.Function):
+    """DisentangledEncoderLayer.forward (disentangled_transformer.py:228-246): post-LN block whose
+    attention adds the c2p / p2c terms from relative rows projected with the content q/k
+    projections (share_att_key, :270,373-377).  ``band`` = the 2N-1 reachable rows of the
+    LayerNormed relative table (row r <-> i - j = r - (N-1)), already in compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, band, wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wi, bi, wout, bout, g2, be2, cfg):
+        B, N, H, eps, scale, w, act = cfg
+        D = x.shape[1]
+        dh = D // H
+        dt = x.dtype
+        wqkv = shadow((wq, wk, wv), dt)
+        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
+        qkv = ops.gemm(x, wqkv, bias=bqkv)
+        tables = None
+        if band is not None:
+            tables = ops.gemm(band, wqkv[:2 * D], bias=bqkv[:2 * D])      # [2N-1, 2D] = (Pq | Pk)
+        attn, lse = _attn_fwd(qkv, B, N, H, dh, tables, scale, w)
+        s1 = ops.gemm(attn, shadow(wo, dt), bias=_f32(bo), residual=x)
+        a, mean1, rstd1 = ops.layernorm_fwd(s1, _f32(g1), _f32(be1), eps)
+        s2, hmid, pre = _mlp_fwd(a, shadow(wi, dt), _f32(bi), shadow(wout, dt), _f32(bout), act, a)
+        y, mean2, rstd2 = ops.layernorm_fwd(s2, _f32(g2), _f32(be2), eps)
+        ctx.save_for_backward(x, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv, tables, attn, lse, s1, mean1, rstd1,
+                              a, hmid, pre, s2, mean2, rstd2)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv, tables, attn, lse, s1, mean1, rstd1, a, hmid, pre, s2,
+         mean2, rstd2) = ctx.saved_tensors
+        B, N, H, eps, scale, w, act = ctx.cfg
+        D = x.shape[1]
+        dh = D // H
+        dt = x.dtype
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dy = dy.contiguous()
+        dg2, dbe2 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2)
+        da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, shadow(wi, dt), shadow(wout, dt), act, hmid, pre, ds2)
+        dg1, dbe1 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1)
+        dbo = ops.colsum(ds1)
+        dwo = _dw(ds1, attn)
+        dattn = _dx(ds1, shadow(wo, dt))
+        dqkv, dtab = _attn_bwd(qkv, B, N, H, dh, tables, scale, w, attn, dattn, lse)
+        wqkv = shadow((wq, wk, wv), dt)
+        dbqkv = ops.colsum(dqkv)
+        dwqkv = _dw(dqkv, x)
+        dx = _dx(dqkv, wqkv, residual=ds1)
+        dband = None
+        if band is not None:
+            dtab_t = dtab.to(dt)
+            ops.colsum(dtab_t, out=dbqkv[:2 * D])
+            ops.gemm(dtab_t, band, trans_a=True, trans_b=False, out=dwqkv[:2 * D], accumulate=True)
+            dband = _dx(dtab_t, wqkv[:2 * D])
+        dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
+        dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
+        return (dx, dband, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg1, dbe1, dwi, dbi, dwout, dbout, dg2, dbe2,
+                None)
+
+
+class DisAttentionFn(torch.autograd.Function):
+    """DisentangledSelfAttention.forward's 'hidden_states' (disentangled_transformer.py:301-355,
+    LAI twin :851-927) for q = k = value = x: three projections, c2p / p2c bias, softmax, PV."""
+
+    @staticmethod
+    def forward(ctx, x, band, wq, bq, wk, bk, wv, bv, cfg):
+        B, N, H, scale, w = cfg
+        D = x.shape[1]
+        dt = x.dtype
+        wqkv = shadow((wq, wk, wv), dt)
+        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
+        qkv = ops.gemm(x, wqkv, bias=bqkv)
+        tables = ops.gemm(band, wqkv[:2 * D], bias=bqkv[:2 * D]) if band is not None else None
+        attn, lse = _attn_fwd(qkv, B, N, H, D // H, tables, scale, w)
+        ctx.save_for_backward(x, band, wq, wk, wv, qkv, tables, attn, lse)
+        ctx.cfg = cfg
+        return attn
+
+    @staticmethod
+    def backward(ctx, dattn):
+        x, band, wq, wk, wv, qkv, tables, attn, lse = ctx.saved_tensors
+        B, N, H, scale, w = ctx.cfg
+        D = x.shape[1]
+        dt = x.dtype
+        dqkv, dtab = _attn_bwd(qkv, B, N, H, D // H, tables, scale, w, attn, dattn.contiguous(), lse)
+        wqkv = shadow((wq, wk, wv), dt)
+        dbqkv = ops.colsum(dqkv)
+        dwqkv = _dw(dqkv, x)
+        dx = _dx(dqkv, wqkv)
+        dband = None
+        if band is not None:
+            dtab_t = dtab.to(dt)
+            ops.colsum(dtab_t, out=dbqkv[:2 * D])
+            ops.gemm(dtab_t, band, trans_a=True, trans_b=False, out=dwqkv[:2 * D], accumulate=True)
+            dband = _dx(dtab_t, wqkv[:2 * D])
+        return (dx, dband, dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:], None)
+
+
+# --------------------------------------------------------------------------- patch embedding
+class PatchEmbedFn(torch.autograd.Function):
+    """tokens[b] = [cls (+ pos[0]); Conv2d(k=s=P)(img[b]) flattened (+ pos[1:])]  as ONE GEMM over
+    gathered patches with the bias / position add / row placement in its epilogue
+    (model.py:52-55,92-99; timm_locality_aware_transformer.py:133-138)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, cls_token, pos_embed, dtype):
+        B, C, Hh, Ww = img.shape
+        D = weight.shape[0]
+        P = weight.shape[2]
+        npatch = (Hh // P) * (Ww // P)
+        N = npatch + 1
+        patches = ops.patchify(img, P, dtype)
+        w2d = shadow(weight, dtype).view(D, C * P * P)
+        pos_t = None
+        if pos_embed is not None:
+            pos_t = shadow(pos_embed, dtype).view(N, D)
+        tok = torch.empty(B * N, D, device=img.device, dtype=dtype)
+        ops.gemm(patches, w2d, bias=_f32(bias), residual=pos_t, res_period=npatch if pos_t is not None else 0,
+                 res_off=1, out=tok, grp=(npatch, N, 1))
+        ops.cls_rows(tok.view(B, N, D), cls_token.detach().view(D),
+                     None if pos_embed is None else pos_embed.detach().view(N, D))
+        ctx.save_for_backward(patches, weight)
+        ctx.dims = (B, C, Hh, Ww, P, N, D)
+        ctx.has_pos = pos_embed is not None
+        ctx.has_bias = bias is not None
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        patches, weight = ctx.saved_tensors
+        B, C, Hh, Ww, P, N, D = ctx.dims
+        dtok3 = dtok.contiguous().view(B, N, D)
+        dpatch_rows = dtok3[:, 1:].reshape(B * (N - 1), D)
+        dw = _dw(dpatch_rows, patches).view(weight.shape)
+        db = ops.colsum(dpatch_rows) if ctx.has_bias else None
+        dcls = torch.zeros(D, device=dtok.device, dtype=torch.float32)
+        dpos = torch.zeros(N, D, device=dtok.device, dtype=torch.float32) if ctx.has_pos else None
+        ops.token_grads(dtok3, dpos, dcls)
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            wt = shadow(weight, dtok.dtype).view(D, C * P * P)
+            dimg = ops.unpatchify(_dx(dpatch_rows, wt), B, C, Hh, Ww, P)
+        return (dimg, dw, db, dcls.view(1, 1, D), None if dpos is None else dpos.view(1, N, D), None)
+
+
+def patch_embed(img, weight, bias, cls_token, pos_embed, dtype):
+    return PatchEmbedFn.apply(img, weight, bias, cls_token, pos_embed, dtype)
+
+
+# --------------------------------------------------------------------------- MLP
+class MlpFn(torch.autograd.Function):
+    """act(x W1^T + b1) W2^T + b2 with the activation fused into the GEMM epilogues."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act):
+        dt = x.dtype
+        y, hmid, pre = _mlp_fwd(x, shadow(w1, dt), _f32(b1), shadow(w2, dt), _f32(b2), act, None)
+        ctx.save_for_backward(x, w1, w2, hmid, pre)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, hmid, pre = ctx.saved_tensors
+        dt = x.dtype
+        dx, dw1, db1, dw2, db2 = _mlp_bwd(dy.contiguous(), x, shadow(w1, dt), shadow(w2, dt), ctx.act, hmid, pre, None)
+        return dx, dw1, db1, dw2, db2, None
+
+
+def mlp(x2d, w1, b1, w2, b2, act='gelu'):
+    return MlpFn.apply(x2d, w1, b1, w2, b2, act)

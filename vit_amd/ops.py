@@ -9,6 +9,11 @@ from . import _lib
 from ._lib import F32, BF16, ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU, check, lib  # noqa: F401
 
 
+# bench.py sets this to a list to collect (kernel, algorithmic flops, start event, end event) per
+# launch: HIP events recorded on the launch stream (torch's current stream) around the kernel.
+KERNEL_TIMER = None
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
@@ -89,11 +94,20 @@ def gemm(a, b, *, trans_a=False, trans_b=True, out=None, out_dtype=None, bias=No
             raise ValueError('gemm: residual shape mismatch')
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous()):
         raise ValueError('gemm: bias must be contiguous fp32 [N]')
+    timer = KERNEL_TIMER
+    if timer is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     st = lib().vitk_gemm(_dt(a), _dt(out), int(trans_a), int(trans_b), M, N, K, float(alpha),
                          pa, lda, pb, ldb, pc, ldc, _ptr(bias), act, _ptr(aux_in), _ptr(aux_out), ld_aux,
                          _ptr(residual), ldr, res_period, res_off, grp_rows, grp_stride, grp_off,
                          int(accumulate), splitk, _stream())
     check(st, 'vitk_gemm')
+    if timer is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        layout = ('T' if trans_a else 'N') + ('T' if trans_b else 'N')
+        timer.append(('gemm_' + layout + ('_bf16' if a.dtype == torch.bfloat16 else '_f32'), 2.0 * M * N * K, e0, e1))
     return out
 
 
@@ -200,9 +214,9 @@ def attn_fwd(qkv_q, qkv_k, qkv_v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w):
 
 
 def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, lse, dq, dk, dv, ld_d, dpk, dpq,
-             workspace=None):
+             workspace=None, ld_dp=None):
     """dq/dk/dv: views into a [B*N, ld_d] buffer (same addressing as q/k/v).  dpk/dpq: fp32
-    [2N-1, H*dh], ACCUMULATED into (caller zeroes).  ``workspace``: optional uint8 scratch of at
+    [2N-1, H*dh] (row stride ld_dp, default H*dh), ACCUMULATED into (caller zeroes).  ``workspace``: optional uint8 scratch of at
     least attn_bwd_workspace_bytes(...) (allocated when not given)."""
     _req_cuda(q, k, v, pk, pq, out, dout, lse, dq, dk, dv, dpk, dpq, workspace)
     need = lib().vitk_attn_bwd_workspace_bytes(_dt(q), B, H, N, dh)
@@ -216,5 +230,5 @@ def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, l
                              _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
                              out.data_ptr(), dout.data_ptr(), H * dh, lse.data_ptr(),
                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d,
-                             _ptr(dpk), _ptr(dpq), H * dh, workspace.data_ptr(), _stream())
+                             _ptr(dpk), _ptr(dpq), H * dh if ld_dp is None else ld_dp, workspace.data_ptr(), _stream())
     check(st, 'vitk_attn_bwd')

@@ -1,0 +1,81 @@
+"""Training-step harness for the hot path: the per-batch sequence of the reference's
+``training()`` loop (train.py:530-554) and the model factory subset of ``build_model``
+(train.py:96-277) that north_star names, on synthetic data.
+
+Not restated: datasets, wandb, checkpoints, the eval loop.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import model as M
+from .disentangled_transformer.disentangled_transformer import DisentangledTransformer
+from .precision import set_compute_dtype
+from .timm_classes.timm_locality_aware_transformer import VisionTransformerLAI
+
+# Presets as the reference names them (README.md:50-54): S/16 = 12 L x 768 (== timm
+# vit_base_patch16_224, train.py:121), B/16 = 24 L x 1024 x 16 h, L/16 = 32 L x 1280 x 16 h.
+PRESETS = {
+    'S': dict(depth=12, dim=768, mlp=3072, heads=12),
+    'B': dict(depth=24, dim=1024, mlp=4096, heads=16),
+    'L': dict(depth=32, dim=1280, mlp=5120, heads=16),
+    'cifar': dict(depth=6, dim=256, mlp=1024, heads=8),
+}
+
+
+def label_smoothing_ce(logits, target, smoothing=0.1):
+    """timm 0.4.5 LabelSmoothingCrossEntropy (train.py:273): (1-s) * NLL + s * mean(-log p)."""
+    logp = F.log_softmax(logits.float(), dim=-1)
+    nll = -logp.gather(-1, target[:, None]).squeeze(1)
+    return ((1.0 - smoothing) * nll + smoothing * (-logp.mean(-1))).mean()
+
+
+def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, num_classes=1000,
+                mask_epochs=None, dtype=torch.bfloat16, device='cuda', **over):
+    """Model factory for the --attention variants on the hot path (train.py:97-253):
+    'transformer' (regular, pre-LN, ReLU), 'transformer_timm_lai', 'disentangled_attention',
+    'disentangled_lai_attention'.  Dropout is 0 (parity and benchmarks are defined at p = 0)."""
+    p = dict(PRESETS[preset], **over)
+    if attention == 'transformer':
+        tr = M.Transformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+                           num_encoder_layers=p['depth'], normalize_before=True)
+        net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                  num_classes=num_classes, transformer=tr)
+    elif attention == 'transformer_timm_lai':
+        net = VisionTransformerLAI(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                   num_classes=num_classes, embed_dim=p['dim'], depth=p['depth'],
+                                   num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'], qkv_bias=True,
+                                   mask_epochs=mask_epochs)
+    elif attention in ('disentangled_attention', 'disentangled_lai_attention'):
+        lai = attention == 'disentangled_lai_attention'
+        tr = DisentangledTransformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+                                     num_encoder_layers=p['depth'], normalize_before=True, pos_att_type='c2p|p2c',
+                                     max_position_embeddings=p['dim'], relative_attention=True, lai=lai,
+                                     mask_epochs=mask_epochs if lai else None)
+        net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                  num_classes=num_classes, transformer=tr)
+    else:
+        raise ValueError(f'unknown attention variant {attention!r}')
+    net = net.to(device)
+    return set_compute_dtype(net, dtype)
+
+
+def takes_epoch(net):
+    return isinstance(net, VisionTransformerLAI) or \
+        isinstance(getattr(net, 'transformer', None), DisentangledTransformer)
+
+
+def train_step(net, optimizer, img, target, epoch=None, smoothing=0.1, reducer=None):
+    """One iteration of train.py:530-554: forward, label-smoothing CE, zero_grad, backward
+    (gradient all-reduce overlapped when ``reducer`` is given), optimizer step.  The reference's
+    clip_grad_norm_ sits before backward on zeroed grads (train.py:544-546) and is a no-op."""
+    out = net(img, epoch) if epoch is not None else net(img)
+    loss = label_smoothing_ce(out, target, smoothing)
+    if reducer is not None:
+        reducer.prepare()          # zeroes the gradient slabs the .grad views live in
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step()
+    return loss.detach()
