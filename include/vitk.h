@@ -1,0 +1,113 @@
+/* vitk.h -- C ABI of libvitk.so: the MI355X (gfx950) kernels behind the ViT encoder hot path of
+ * dinkofranceschi/ViT.
+ *
+ * The reference has no FFI / operator interface of its own (it is pure PyTorch); each entry
+ * point below cites the reference code (file:line under /root/reference) whose aten-op sequence
+ * it replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless stated otherwise;
+ *   - dtype codes: VITK_F32 = 0, VITK_BF16 = 1 (the element type of the "T" tensors); biases,
+ *     LayerNorm affine parameters, statistics and parameter gradients are always fp32;
+ *   - a row-major matrix is (pointer, leading dimension in ELEMENTS); rows must be 16-byte aligned
+ *     where stated; nothing is allocated, nothing synchronises, work is queued on `stream`
+ *     (a hipStream_t passed as void*);
+ *   - return 0 on success, nonzero on error (1 bad argument, 2 HIP launch error, 3 workspace);
+ *     vitk_last_error() returns the calling thread's last message.  No C++ exception crosses.
+ */
+#ifndef VITK_H
+#define VITK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITK_F32 0
+#define VITK_BF16 1
+
+/* GEMM epilogue activations */
+#define VITK_ACT_NONE 0
+#define VITK_ACT_GELU 1   /* erf GELU (nn.GELU, timm Mlp); aux_out receives the pre-activation */
+#define VITK_ACT_RELU 2
+#define VITK_ACT_DGELU 3  /* out = (A.B) * gelu'(aux_in),  aux_in = saved pre-activation */
+#define VITK_ACT_DRELU 4  /* out = (A.B) * (aux_in > 0),   aux_in = saved activation output */
+
+int vitk_version(void);
+const char* vitk_last_error(void);
+
+/* C = epilogue(alpha * op(A) op(B) + bias) [+ residual]      (MFMA, fp32 accumulate)
+ * Replaces nn.Linear forward/backward everywhere on the path: qkv / proj / Mlp fc1,fc2
+ * (timm_classes/timm_locality_aware_transformer.py:48,77,94), query/key/value_proj,
+ * dense_AttnOut, dense_intermediate (+GELU), dense_out (disentangled_transformer.py:854-856,
+ * 188,184-185,194), linear1/linear2 (model.py:202), head (model.py:65), and the patch-embed
+ * Conv2d(k = s = P) as a GEMM over gathered patches (model.py:92-99).
+ * op(A) is M x K: transA = 0 -> A stored [M][lda], 1 -> stored [K][lda] (dW = dY^T X).
+ * op(B) is K x N: transB = 1 -> B stored [N][ldb] (nn.Linear weight), 0 -> stored [K][ldb] (dX = dY W).
+ * c_dtype: output type (bf16 inputs may write fp32: parameter gradients).
+ * bias [N] fp32 or NULL.  aux_in / aux_out / residual: T matrices (ld_aux, ldr) or NULL.
+ * res_period > 0: residual row = res_off + (row % res_period) (position embedding broadcast).
+ * grp_rows > 0: output row r goes to (r / grp_rows) * grp_stride + grp_off + r % grp_rows
+ *               (patch rows into the [B][N][D] token matrix, skipping each image's class row).
+ * accumulate: C += (fp32 C only).  splitk: 0 = auto, > 1 forces split-K (fp32 C, linear epilogue). */
+int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, float alpha,
+              const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+              const float* bias, int act, const void* aux_in, void* aux_out, long ld_aux,
+              const void* residual, long ldr, int res_period, int res_off,
+              int grp_rows, int grp_stride, int grp_off, int accumulate, int splitk, void* stream);
+
+/* nn.LayerNorm over rows of length D (D % 8 == 0, D <= 2048), one wave per row.
+ * timm_locality_aware_transformer.py:87,92,123 (eps 1e-6); disentangled_transformer.py:99,173,180
+ * (eps 1e-5); model.py:22,44.  mean / rstd [rows] fp32 are saved for backward (may be NULL). */
+int vitk_layernorm_fwd(int dtype, int rows, int D, const void* x, long ldx, const float* gamma,
+                       const float* beta, float eps, void* y, long ldy, float* mean, float* rstd,
+                       void* stream);
+/* dx = LN'(dy) [+ add] (add = the residual branch's gradient); dgamma / dbeta [D] fp32 are
+ * ACCUMULATED into (zero them for a fresh sum). */
+int vitk_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, const void* x, long ldx,
+                       const float* mean, const float* rstd, const float* gamma, const void* add,
+                       long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, void* stream);
+
+/* out[n] += sum_m X[m][n]: bias gradients of every nn.Linear above (autograd of addmm). */
+int vitk_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, void* stream);
+
+/* direction 0: fp32 -> bf16, 1: bf16 -> fp32, n elements (weight shadows for the bf16 path). */
+int vitk_cast(int direction, long n, const void* src, void* dst, void* stream);
+
+/* Patch gather / scatter for Conv2d(kernel = stride = P): out[(b*nph+ph)*npw+pw][(c*P+py)*P+px] =
+ * img[b][c][ph*P+py][pw*P+px]  (model.py:92-99: proj(x).flatten(2).transpose(1,2)). */
+int vitk_patchify(int img_dtype, int out_dtype, int B, int C, int H, int W, int P, const void* img,
+                  void* out, void* stream);
+int vitk_unpatchify(int dtype, int B, int C, int H, int W, int P, const void* dpatch, float* dimg,
+                    void* stream);
+/* x[b][0][:] = cls + pos[0] (pos may be NULL): torch.cat((cls_tokens, x)) [+ pos_embed]
+ * (model.py:54-55; timm_locality_aware_transformer.py:136-138). */
+int vitk_cls_rows(int dtype, int B, int N, int D, const float* cls, const float* pos, void* x, void* stream);
+/* dpos[n][d] += sum_b dx[b][n][d];  dcls[d] += sum_b dx[b][0][d]  (either may be NULL). */
+int vitk_token_grads(int dtype, int B, int N, int D, const void* dx, float* dpos, float* dcls, void* stream);
+
+/* Fused attention forward: out = softmax(scale * (Q K^T + c2p + p2c) restricted to |i-j| <= band_w) V.
+ * Replaces AttentionLAI.forward's q@k^T / masked_fill / softmax / @v
+ * (timm_locality_aware_transformer.py:51-76 with get_attn_mask :11-21) and
+ * Disentangled[LAI]SelfAttention.forward + disentangled_attention_bias
+ * (disentangled_transformer.py:324-347,357-426 / :875-919,929-998).
+ * q, k, v: element (b, n, h, d) at ((b*N + n) * ld + h*dh + d) (views into one packed qkv buffer).
+ * pk / pq: the projected relative tables restricted to the 2N-1 reachable rows,
+ *          row r <-> i - j = r - (N-1), element (r, h, d) at r * ld_p + h*dh + d; both NULL for
+ *          plain / LAI attention.  score = Q_i.K_j + Q_i.pk[i-j] + K_j.pq[i-j].
+ * band_w < 0: no mask.  out [B*N][ldo]; lse [B][H][N] fp32 (log-sum-exp, saved for backward). */
+int vitk_attn_fwd(int dtype, int B, int H, int N, int dh, const void* q, const void* k, const void* v,
+                  long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
+                  void* out, long ldo, float* lse, void* stream);
+
+/* Fused attention backward (autograd of the above): dq / dk / dv (T, same addressing with ld_d)
+ * and, with tables, dpk / dpq fp32 [2N-1][ld_dp] ACCUMULATED into.  `workspace` must hold
+ * vitk_attn_bwd_workspace_bytes(...) bytes (16-byte aligned). */
+long vitk_attn_bwd_workspace_bytes(int dtype, int B, int H, int N, int dh);
+int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void* q, const void* k, const void* v,
+                  long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
+                  const void* out, const void* dout, long ldo, const float* lse,
+                  void* dq, void* dk, void* dv, long ld_d, float* dpk, float* dpq, long ld_dp,
+                  void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H */

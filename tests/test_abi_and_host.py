@@ -1,0 +1,122 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/vitk.h declares
+(no compute calls), the ctypes table matches the header, the drop-in modules keep the reference's
+state_dict keys, and host-side logic (LAI schedule, band rows, flop model) is right."""
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import golden_inputs as gi  # noqa: E402
+from oracle import ref_cpu as R  # noqa: E402
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'vitk.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(vitk_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vit_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'run `python -m vit_amd._build` first'
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), f'{s} declared in include/vitk.h but not exported'
+    for s in _lib._SIGNATURES:
+        assert s in syms, f'{s} bound by ctypes but not declared in include/vitk.h'
+    assert L.vitk_version() >= 1
+
+
+def test_header_arity_matches_ctypes_table():
+    from vit_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'vitk.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    for name, sig in _lib._SIGNATURES.items():
+        m = re.search(r'\b' + name + r'\s*\(([^;]*?)\)\s*;', text, flags=re.S)
+        assert m, name
+        args = m.group(1).strip()
+        n = 0 if args in ('', 'void') else len(args.split(','))
+        assert n == len(sig[0]), (name, n, len(sig[0]))
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    from vit_amd import ops
+    from vit_amd._lib import VitkError
+    with pytest.raises(VitkError):
+        ops.gemm(torch.randn(8, 16), torch.randn(8, 16))
+
+
+def test_state_dict_keys_match_reference_named_oracle():
+    """The oracle's keys are the reference's (the golden tests load reference-keyed values into it)."""
+    from vit_amd import model as M
+    from vit_amd.disentangled_transformer.disentangled_transformer import DisentangledTransformer
+    from vit_amd.timm_classes.timm_locality_aware_transformer import AttentionLAI, VisionTransformerLAI
+    me = gi.LAI_MASK_EPOCHS
+
+    def shapes(m):
+        return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    kw = dict(d_model=128, dropout=0.0, nhead=4, dim_feedforward=256, num_encoder_layers=2, normalize_before=True,
+              pos_att_type='c2p|p2c', max_position_embeddings=128, relative_attention=True, lai=True, mask_epochs=me)
+    mine = M.VisionTransformer(img_size=32, patch_size=4, num_classes=10, transformer=DisentangledTransformer(**kw))
+    ref = R.RefVisionTransformer(img_size=32, patch_size=4, num_classes=10, transformer=R.RefDisentangledTransformer(**kw))
+    assert shapes(mine) == shapes(ref)
+    kw = dict(d_model=64, dropout=0.0, nhead=4, dim_feedforward=128, num_encoder_layers=2, normalize_before=True)
+    mine = M.VisionTransformer(img_size=32, patch_size=4, num_classes=10, transformer=M.Transformer(**kw))
+    ref = R.RefVisionTransformer(img_size=32, patch_size=4, num_classes=10, transformer=R.RefTransformer(**kw))
+    assert shapes(mine) == shapes(ref)
+    kw = dict(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2, num_heads=4, mask_epochs=me)
+    assert shapes(VisionTransformerLAI(**kw)) == shapes(R.RefVisionTransformerLAI(**kw))
+    assert shapes(AttentionLAI(64, 4, qkv_bias=True)) == shapes(R.RefAttentionLAI(64, 4, qkv_bias=True))
+
+
+def test_lai_mask_and_schedule_match_golden():
+    import hashlib
+    import numpy as np
+    from vit_amd.timm_classes.timm_locality_aware_transformer import get_attn_mask, lai_stage_width
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'lai_masks.npz'))
+    for N in (65, 197, 577):
+        for w in (8, 12, 18, 20):
+            m = get_attn_mask(N, w)
+            sha = np.frombuffer(hashlib.sha256(m.numpy().tobytes()).digest(), dtype=np.uint8)
+            assert np.array_equal(sha, g[f'sha_{N}_{w}'])
+    me = gi.LAI_MASK_EPOCHS
+    assert [lai_stage_width(e, me) for e in (0, 9, 10, 19, 20, 29, 30, 39, 40, 99)] == \
+        [8, 8, 12, 12, 18, 18, 20, 20, None, None]
+    assert lai_stage_width(3, None) is None
+
+
+def test_band_rows_and_relative_position():
+    from vit_amd.disentangled_transformer.disentangled_transformer import band_rows
+    from vit_amd.utils.ops import build_relative_position
+    rel = torch.arange(2 * 8 * 3, dtype=torch.float32).view(16, 3)   # span 8
+    N = 5
+    band = band_rows(rel, N, 8)
+    idx = R.dis_delta_index(N, 8)                                     # [N,N] clamp(i-j+S)
+    for i in range(N):
+        for j in range(N):
+            assert torch.equal(band[i - j + N - 1], rel[idx[i, j]])
+    big = band_rows(rel, 12, 8)                                       # clamp active: |delta| > span
+    assert torch.equal(big[0], rel[0]) and torch.equal(big[-1], rel[15])
+    rp = build_relative_position(4, 4)
+    assert rp.shape == (1, 4, 4) and rp.dtype == torch.long and rp[0, 3, 1] == 2 and rp[0, 0, 2] == -2
+
+
+def test_flop_model_matches_survey_table():
+    sys.path.insert(0, ROOT)
+    import bench
+    from vit_amd.train import PRESETS
+    f = bench.train_flops_per_image('disentangled_lai_attention', PRESETS['B'], 197, 16, 1000, 128, -1) / 1e9
+    assert abs(f - 381.7) < 0.5                       # headline unmasked
+    f = bench.train_flops_per_image('disentangled_lai_attention', PRESETS['B'], 197, 16, 1000, 128, 8) / 1e9
+    assert abs(f - 360.7) < 0.5
+    f = bench.train_flops_per_image('transformer_timm_lai', PRESETS['S'], 197, 16, 1000, 128, 20) / 1e9
+    assert abs(f - 101.9) < 0.3
