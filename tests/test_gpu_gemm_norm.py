@@ -159,3 +159,61 @@ def test_patchify_roundtrip():
     assert torch.equal(pat, ref)
     assert torch.equal(ops.unpatchify(pat, B, C, H, H, P), img)
     assert torch.equal(ops.patchify(img, P, torch.bfloat16), ref.bfloat16())
+
+
+BIG_SHAPES = [(520, 1000, 192), (1032, 536, 320), (2048, 1024, 128), (776, 776, 448)]
+
+
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', BIG_SHAPES)
+def test_gemm256_layouts(ta, tb, M, N, K):
+    """Shapes routed to the 256x256 direct-to-LDS kernel (bf16, K % 64 == 0, M*N >= 512^2)."""
+    ops = _ops()
+    torch.manual_seed(M + 3 * N + K)
+    a = torch.randn((K, M) if ta else (M, K), device='cuda').bfloat16()
+    b = torch.randn((N, K) if tb else (K, N), device='cuda').bfloat16()
+    ref = (a.float().t() if ta else a.float()).double() @ (b.float().t() if tb else b.float()).double()
+    out = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32)
+    assert relerr(out, ref) < 1e-5
+    assert relerr(ops.gemm(a, b, trans_a=ta, trans_b=tb), ref) < 1e-2
+    sk = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, splitk=2)
+    assert relerr(sk, ref) < 1e-5
+
+
+def test_gemm256_epilogues():
+    ops = _ops()
+    torch.manual_seed(11)
+    M, N, K = 1000, 776, 256
+    a = torch.randn(M, K, device='cuda').bfloat16()
+    w = (torch.randn(N, K, device='cuda') / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device='cuda')
+    res = torch.randn(M, N, device='cuda').bfloat16()
+    lin = a.float() @ w.float().t() + bias
+    tol = 1.5e-2
+    assert relerr(ops.gemm(a, w, bias=bias, residual=res), lin + res.float()) < tol
+    pre = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    y = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU, aux_out=pre)
+    assert relerr(pre, lin) < tol and relerr(y, torch.nn.functional.gelu(lin)) < tol
+    assert relerr(ops.gemm(a, w, bias=bias, act=ops.ACT_RELU), torch.relu(lin)) < tol
+    h = torch.randn(M, N, device='cuda').bfloat16()
+    hf = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hf).sum().backward()
+    raw = a.float() @ w.float().t()
+    assert relerr(ops.gemm(a, w, act=ops.ACT_DGELU, aux_in=h), raw * hf.grad) < tol
+    assert relerr(ops.gemm(a, w, act=ops.ACT_DRELU, aux_in=h), raw * (h.float() > 0)) < tol
+    acc0 = torch.randn(M, N, device='cuda')
+    acc = acc0.clone()
+    ops.gemm(a, w, out=acc, accumulate=True, splitk=2)
+    assert relerr(acc, acc0 + raw) < 1e-5
+    # strided operands (column slices of wider buffers), as the attention backward feeds them
+    wide = torch.randn(M, 3 * K, device='cuda').bfloat16()
+    sl = wide[:, K:2 * K]
+    assert relerr(ops.gemm(sl, w, out_dtype=torch.float32), sl.float() @ w.float().t()) < 1e-5
+    # grouped rows + periodic residual (patch-embed epilogue)
+    per, groups = 200, 5
+    pos = torch.randn(per + 1, N, device='cuda').bfloat16()
+    tok = torch.zeros(groups * (per + 1), N, device='cuda', dtype=torch.bfloat16)
+    ops.gemm(a, w, bias=bias, residual=pos, res_period=per, res_off=1, out=tok, grp=(per, per + 1, 1))
+    want = torch.zeros(groups, per + 1, N, device='cuda')
+    want[:, 1:] = lin.view(groups, per, N) + pos.float()[1:]
+    assert relerr(tok.float().view(groups, per + 1, N), want) < tol

@@ -174,7 +174,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
         ilo = (ilo / 32) * 32;
     }
 
+    // LAI band narrow enough: every live tile's relative rows fit ONE window, staged once
+    // (rows delta in [-16 cmax - 15, 16 cmax + 15], cmax = last live tile diagonal).
+    const int cmax = p.w >= 0 ? (p.w + 15) / 16 : 0;
+    const bool win_fixed = BIAS && p.w >= 0 && 32 * cmax + 32 <= WIN;
     stage_rows<T, DKB>(Ks, K, p.ld, kb0, KB, 0, N, dh, tid, NTH);
+    if (win_fixed) {
+        const int r_lo = -16 * cmax - 15 + (N - 1);
+        stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, 32 * cmax + 32, 0, 2 * N - 1, dh, tid, NTH);
+        stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, 32 * cmax + 32, 0, 2 * N - 1, dh, tid, NTH);
+    }
     __syncthreads();
 
     Frag<T> kf[KTW][DKB], vf[KTW][DKB];
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
         __syncthreads();
         stage_rows<T, DKB>(Qs, Q, p.ld, i0, 32, 0, N, dh, tid, NTH);
         stage_rows<T, DKB>(dOs, dO, p.ldo, i0, 32, 0, N, dh, tid, NTH);
-        if (BIAS) {
+        if (BIAS && !win_fixed) {
             const int r_lo = i0 - kb0 - KB + 1 + (N - 1);  // table row of window row 0
             stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WIN, 0, 2 * N - 1, dh, tid, NTH);
             stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WIN, 0, 2 * N - 1, dh, tid, NTH);
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
                     float* ds = dss + kt * 16 * DSLD;
                     const bool dead = kj0 >= N || qi0 >= N ||
                                       (p.w >= 0 && (kj0 > qi0 + 15 + p.w || kj0 + 15 < qi0 - p.w));
-                    const int rel = 16 * qt - (kw0 + 16 * kt) + KB - 16;
+                    const int rel = win_fixed ? (qi0 - kj0 + 16 * cmax) : (16 * qt - (kw0 + 16 * kt) + KB - 16);
                     f32x4 pv = {0.f, 0.f, 0.f, 0.f}, dsv = {0.f, 0.f, 0.f, 0.f};
                     if (!dead) {
                         const f32x4 raw = score_tile<T, DKB, BIAS, false>(qf, kf[kt], Pks, Pqs, rel, xs, ys, lane);
@@ -392,9 +401,36 @@ template <typename T, int DKB> struct RelCfg {
     }
 };
 
+// Everything one tile pair needs from HBM, fetched one pair ahead of its use (the loads stay in
+// flight under the previous pair's MFMAs and LDS round trips).
+template <typename T, int DKB> struct RelPrefetch {
+    static constexpr int CPR = ACfg<T, DKB>::CPR;
+    static constexpr int CH = 32 * CPR / 64;     // 16-byte chunks per lane for a 32-row image
+    u32x4 q[CH], k[CH];
+};
+
 template <typename T, int DKB>
-__global__ __launch_bounds__(256) void attn_bwd_rel_kernel(const AttnBwdParams p) {
+__device__ __forceinline__ void rel_fetch(RelPrefetch<T, DKB>& pf, const AttnBwdParams& p, int h, int b, int i0,
+                                          int j0, int ilim, int jlim, int lane) {
     using C = ACfg<T, DKB>;
+    const int N = p.N, dh = p.dh;
+    const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
+    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
+#pragma unroll
+    for (int c = 0; c < RelPrefetch<T, DKB>::CH; ++c) {
+        const int idx = lane + 64 * c;
+        const int r = idx / C::CPR, d = (idx - r * C::CPR) * C::EPC;
+        pf.q[c] = u32x4{0, 0, 0, 0};
+        pf.k[c] = u32x4{0, 0, 0, 0};
+        if (i0 + r < ilim && d < dh) pf.q[c] = *reinterpret_cast<const u32x4*>(Q + (long)(i0 + r) * p.ld + d);
+        if (j0 + r < jlim && d < dh) pf.k[c] = *reinterpret_cast<const u32x4*>(K + (long)(j0 + r) * p.ld + d);
+    }
+}
+
+template <typename T, int DKB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_rel_kernel(const AttnBwdParams p) {
+    using C = ACfg<T, DKB>;
+    using PF = RelPrefetch<T, DKB>;
     constexpr int ASTR = C::ASTR;
     constexpr int ND = 2 * DKB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -407,25 +443,31 @@ __global__ __launch_bounds__(256) void attn_bwd_rel_kernel(const AttnBwdParams p
     float* ys = xs + SCR_FLOATS;
     float* dss = ys + SCR_FLOATS;
 
-    const int N = p.N, dh = p.dh, H = p.H;
+    const int N = p.N, dh = p.dh;
     const int NT = (N + 15) / 16;
-    const int cw = blockIdx.x * 4 + wave;   // wrapped tile diagonal
+    // Work items.  Narrow LAI band: one live tile diagonal each (c = item - cmax).  Otherwise the
+    // diagonals are paired (c, c - NT) so every item walks NT tiles.
+    const int cmax = p.w >= 0 ? min((p.w + 15) / 16, NT - 1) : NT - 1;
+    const bool banded = 2 * cmax + 1 < NT;
+    const int nitems = banded ? 2 * cmax + 1 : NT;
+    const int item = blockIdx.x * 4 + wave;
     const int h = blockIdx.y;
     const int b_lo = blockIdx.z * p.bgroup, b_hi = min(p.B, b_lo + p.bgroup);
-    if (cw >= NT) return;   // whole wave leaves; no workgroup barriers below
+    if (item >= nitems || b_lo >= b_hi) return;   // whole wave leaves; no workgroup barriers below
 
-    constexpr float LOG2E = 1.4426950408889634f;
-    const float sc2 = p.scale * LOG2E;
+    const float sc2 = p.scale * 1.4426950408889634f;
     const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
     const T* PQ = reinterpret_cast<const T*>(p.pq) + h * dh;
 
-    for (int pass = 0; pass < 2; ++pass) {
-        const int c = pass == 0 ? cw : cw - NT;
-        if (pass == 1 && cw == 0) break;
+    for (int pass = 0; pass < (banded ? 1 : 2); ++pass) {
+        const int c = banded ? item - cmax : (pass == 0 ? item : item - NT);
+        if (!banded && pass == 1 && item == 0) break;
         const int ac = c < 0 ? -c : c;
         if (p.w >= 0 && 16 * ac - 15 > p.w) continue;   // whole diagonal outside the LAI band
         const int ntile = NT - ac;
+        const int npair = (ntile + 1) / 2;
         const int ibase = 16 * (c > 0 ? c : 0), jbase = 16 * (c < 0 ? -c : 0);
+        const int ilim = min(N, ibase + 16 * ntile), jlim = min(N, jbase + 16 * ntile);
         const int R0 = 16 * c - 15 + (N - 1);            // table row of t = 0
 
         Frag<T> pkf[2][DKB], pqf[2][DKB];
@@ -452,83 +494,104 @@ __global__ __launch_bounds__(256) void attn_bwd_rel_kernel(const AttnBwdParams p
                 apq[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 
-        for (int b = b_lo; b < b_hi; ++b) {
-            const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
-            const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
+        const int total = (b_hi - b_lo) * npair;
+        PF pf;
+        rel_fetch<T, DKB>(pf, p, h, b_lo, ibase, jbase, ilim, jlim, lane);
+        for (int it = 0; it < total; ++it) {
+            const int m = 2 * (it % npair);
+            const int i0 = ibase + 16 * m, j0 = jbase + 16 * m;
+            // prefetched rows -> this wave's LDS images (rows past the diagonal's end are zero)
+#pragma unroll
+            for (int cch = 0; cch < PF::CH; ++cch) {
+                const int idx = lane + 64 * cch;
+                const int r = idx / C::CPR, d = (idx - r * C::CPR) * C::EPC;
+                *reinterpret_cast<u32x4*>(Qw + r * ASTR + d) = pf.q[cch];
+                *reinterpret_cast<u32x4*>(Kw + r * ASTR + d) = pf.k[cch];
+            }
+            const int b = b_lo + it / npair;
             const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
             const T* dO = reinterpret_cast<const T*>(p.dout) + (long)b * N * p.ldo + h * dh;
-            const float* lse = p.lse + ((long)b * H + h) * N;
-            const float* delta = p.delta + ((long)b * H + h) * N;
-            for (int m = 0; m < ntile; m += 2) {
-                const int i0 = ibase + 16 * m, j0 = jbase + 16 * m;
-                // stage the pair's 32 query rows and 32 key rows (rows past the diagonal's last
-                // tile are zero-filled so they contribute nothing)
-                const int ilim = min(N, ibase + 16 * ntile), jlim = min(N, jbase + 16 * ntile);
-                stage_rows<T, DKB>(Qw, Q, p.ld, i0, 32, 0, ilim, dh, lane, 64);
-                stage_rows<T, DKB>(Kw, K, p.ld, j0, 32, 0, jlim, dh, lane, 64);
-                wave_lds_sync();
+            const float* lse = p.lse + ((long)b * p.H + h) * N;
+            const float* delta = p.delta + ((long)b * p.H + h) * N;
+            Frag<T> vf[2][DKB], dof[2][DKB];
+            float lse2[2][4], dl[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int kb = 0; kb < DKB; ++kb) {
+                    row_frag_global<T>(vf[u][kb], V, p.ld, j0 + 16 * u + li, N, dh, kb, lane);
+                    row_frag_global<T>(dof[u][kb], dO, p.ldo, i0 + 16 * u + li, N, dh, kb, lane);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qc = min(i0 + 16 * u + 4 * g + r, N - 1);
+                    lse2[u][r] = lse[qc] * 1.4426950408889634f;
+                    dl[u][r] = delta[qc];
+                }
+            }
+            if (it + 1 < total) {
+                const int nb = b_lo + (it + 1) / npair, nm = 2 * ((it + 1) % npair);
+                rel_fetch<T, DKB>(pf, p, h, nb, ibase + 16 * nm, jbase + 16 * nm, ilim, jlim, lane);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qi0 = i0 + 16 * u, kj0 = j0 + 16 * u;
+                float* ds = dss + u * 16 * DSLD;
+                f32x4 dsv = {0.f, 0.f, 0.f, 0.f};
+                if (m + u < ntile) {
+                    Frag<T> qf[DKB], kf[DKB];
+#pragma unroll
+                    for (int kb = 0; kb < DKB; ++kb) {
+                        row_frag<T, DKB>(qf[kb], Qw, 16 * u, kb, lane);
+                        row_frag<T, DKB>(kf[kb], Kw, 16 * u, kb, lane);
+                    }
+                    const f32x4 raw = score_tile_diag<T, DKB>(qf, kf, pkf, pqf, xs, ys, lane);
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < DKB; ++kb) dp = mma(dof[u][kb], vf[u][kb], dp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qi = qi0 + 4 * g + r, kj = kj0 + li;
+                        const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
+                        const float pe = ok ? exp2f(raw[r] * sc2 - lse2[u][r]) : 0.f;
+                        dsv[r] = pe * (dp[r] - dl[u][r]) * p.scale;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[(4 * g + r) * DSLD + li] = dsv[r];
+            }
+            wave_lds_sync();
+            // dPk[t][d] += sum_ii Sx[t][ii] Q[ii][d],  dPq[t][d] += sum_jj Sy[t][jj] K[jj][d]
+            // K dimension = the pair's 32 rows: k = 8g+e -> tile (g >> 1), local row 8(g&1)+e
+            {
+                const float* ds = dss + (g >> 1) * 16 * DSLD;
+                const int lbase = 8 * (g & 1);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int qi0 = i0 + 16 * u, kj0 = j0 + 16 * u;
-                    float* ds = dss + u * 16 * DSLD;
-                    f32x4 dsv = {0.f, 0.f, 0.f, 0.f};
-                    if (m + u < ntile) {
-                        Frag<T> qf[DKB], kf[DKB], vf[DKB], dof[DKB];
+                    const int t = li + 16 * u;
+                    Frag<T> ax, ay;
 #pragma unroll
-                        for (int kb = 0; kb < DKB; ++kb) {
-                            row_frag<T, DKB>(qf[kb], Qw, 16 * u, kb, lane);
-                            row_frag<T, DKB>(kf[kb], Kw, 16 * u, kb, lane);
-                            row_frag_global<T>(vf[kb], V, p.ld, kj0 + li, N, dh, kb, lane);
-                            row_frag_global<T>(dof[kb], dO, p.ldo, qi0 + li, N, dh, kb, lane);
-                        }
-                        const f32x4 raw = score_tile_diag<T, DKB>(qf, kf, pkf, pqf, xs, ys, lane);
-                        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kb = 0; kb < DKB; ++kb) dp = mma(dof[kb], vf[kb], dp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int qi = qi0 + 4 * g + r, kj = kj0 + li;
-                            const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
-                            const int qc = min(qi, N - 1);
-                            const float pe = ok ? exp2f(raw[r] * sc2 - lse[qc] * LOG2E) : 0.f;
-                            dsv[r] = pe * (dp[r] - delta[qc]) * p.scale;
-                        }
+                    for (int e = 0; e < 8; ++e) {
+                        const int l = lbase + e;
+                        const int jj = l + 15 - t;   // Sx[t][ii = l] = dS[l][l + 15 - t]
+                        const float vx = ds[l * DSLD + min(max(jj, 0), 15)];
+                        frag_set(ax, e, (jj >= 0 && jj < 16) ? vx : 0.f);
+                        const int ii = l + t - 15;   // Sy[t][jj = l] = dS[l + t - 15][l]
+                        const float vy = ds[min(max(ii, 0), 15) * DSLD + l];
+                        frag_set(ay, e, (ii >= 0 && ii < 16) ? vy : 0.f);
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ds[(4 * g + r) * DSLD + li] = dsv[r];
-                }
-                wave_lds_sync();
-                // dPk[t][d] += sum_ii Sx[t][ii] Q[ii][d],  dPq[t][d] += sum_jj Sy[t][jj] K[jj][d]
-                // K dimension = the pair's 32 rows: k = 8g+e -> tile (g >> 1), local row 8(g&1)+e
-                {
-                    const float* ds = dss + (g >> 1) * 16 * DSLD;
-                    const int lbase = 8 * (g & 1);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int t = li + 16 * u;
-                        Frag<T> ax, ay;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int l = lbase + e;
-                            const int jj = l + 15 - t;   // Sx[t][ii = l] = dS[l][l + 15 - t]
-                            const float vx = ds[l * DSLD + min(max(jj, 0), 15)];
-                            frag_set(ax, e, (jj >= 0 && jj < 16) ? vx : 0.f);
-                            const int ii = l + t - 15;   // Sy[t][jj = l] = dS[l + t - 15][l]
-                            const float vy = ds[min(max(ii, 0), 15) * DSLD + l];
-                            frag_set(ay, e, (ii >= 0 && ii < 16) ? vy : 0.f);
-                        }
-#pragma unroll
-                        for (int dt = 0; dt < ND; ++dt) {
-                            Frag<T> bq, bk;
-                            col_frag(bq, Qw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
-                            col_frag(bk, Kw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
-                            apk[u][dt] = mma(ax, bq, apk[u][dt]);
-                            apq[u][dt] = mma(ay, bk, apq[u][dt]);
-                        }
+                    for (int dt = 0; dt < ND; ++dt) {
+                        Frag<T> bq, bk;
+                        col_frag(bq, Qw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
+                        col_frag(bk, Kw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
+                        apk[u][dt] = mma(ax, bq, apk[u][dt]);
+                        apq[u][dt] = mma(ay, bk, apq[u][dt]);
                     }
                 }
-                wave_lds_sync();
             }
+            wave_lds_sync();
         }
         // flush: acc[u][dt][r] = dP*[t = 16u+4g+r][d = 16dt+li]
 #pragma unroll
@@ -588,7 +651,10 @@ template <typename T, int DKB> static void rel_launch(const AttnBwdParams& p, in
         attr = true;
     }
     const int NT = (p.N + 15) / 16;
-    dim3 grid((NT + 3) / 4, p.H, zgroups);
+    int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
+    if (cmax > NT - 1) cmax = NT - 1;
+    const int nitems = (2 * cmax + 1 < NT) ? 2 * cmax + 1 : NT;
+    dim3 grid((nitems + 3) / 4, p.H, zgroups);
     hipLaunchKernelGGL((attn_bwd_rel_kernel<T, DKB>), grid, dim3(256), lds, st, p);
 }
 
@@ -660,12 +726,13 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
     p.dpk = dpk; p.dpq = dpq; p.ld_dp = ld_dp;
     p.B = B; p.H = H; p.N = N; p.dh = dh;
     p.scale = scale; p.w = band_w;
-    // batches per wave in the table-gradient kernel: enough waves to fill the chip, few flushes
+    // batches per wave in the table-gradient kernel: enough waves to fill the chip (the kernel is
+    // LDS-limited to ~8 waves per CU), few atomic flushes (one per wave)
     const int NT = (N + 15) / 16;
-    int live_diags = NT;
-    if (band_w >= 0) live_diags = 1 + 2 * ((band_w + 15) / 16);
-    if (live_diags > NT) live_diags = NT;
-    int zgroups = (2048 + live_diags * H - 1) / (live_diags * H);
+    int cmax = band_w >= 0 ? (band_w + 15) / 16 : NT - 1;
+    if (cmax > NT - 1) cmax = NT - 1;
+    const int nitems = (2 * cmax + 1 < NT) ? 2 * cmax + 1 : NT;
+    int zgroups = (3072 + nitems * H - 1) / (nitems * H);
     if (zgroups > B) zgroups = B;
     if (zgroups < 1) zgroups = 1;
     p.bgroup = (B + zgroups - 1) / zgroups;

@@ -21,39 +21,12 @@
 //   * split-K (fp32 atomics) for the dW shapes whose output has too few tiles to fill 256 CUs.
 //   * XCD-aware, grouped tile order: workgroups that share an A row panel / B column panel
 //     run on the same XCD (private L2) back to back.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace vitk {
 
 constexpr int BM = 128, BN = 128;
 constexpr int STAGE_BYTES = 18432;  // max(KC image 128 rows x 128 B, KM image BK rows x 288|576 B)
-
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_DGELU = 3, ACT_DRELU = 4 };
-
-struct GemmParams {
-    const void* A;
-    const void* B;
-    void* C;
-    int M, N, K;
-    long lda, ldb, ldc;
-    const float* bias;     // [N] fp32 or null
-    int act;
-    const void* aux_in;    // act 3/4: pre-activation (dgelu) or activation output (drelu), dtype T
-    void* aux_out;         // act 1: pre-activation copy, dtype T
-    long ld_aux;
-    const void* residual;  // dtype T, added after the activation
-    long ldr;
-    int res_period;        // 0: residual row = output row; >0: row = res_off + (r % res_period)
-    int res_off;
-    int grp_rows;          // 0: identity; >0: out row = (r / grp_rows) * grp_stride + grp_off + r % grp_rows
-    int grp_stride, grp_off;
-    int accumulate;        // C += (fp32 C only)
-    int splitk;
-    int a_vec_ok, b_vec_ok;  // 16-byte vector loads legal (base + ld aligned)
-    int c_vec_ok;            // vector epilogue legal (C/aux/residual bases + lds aligned, N % 4 == 0)
-    float alpha;
-    int tiles_m, tiles_n;
-};
 
 template <typename T> struct Cfg {
     static constexpr int EPC = 16 / sizeof(T);          // elements per 16-byte chunk
@@ -160,23 +133,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- tile schedule: XCD-aware (bijective) remap, then groups of 8 row panels ----------
+    // ---- tile schedule (XCD-aware, grouped: gemm_common.h) -----------------------------------
     const int ntiles = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    const int split = bid / ntiles;
-    bid -= split * ntiles;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
-    constexpr int GROUP_M = 8;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int grp = bid / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsize = min(p.tiles_m - first_m, GROUP_M);
-    const int in_grp = bid - grp * per_group;
-    const int tile_m = first_m + in_grp % gsize;
-    const int tile_n = in_grp / gsize;
+    const int split = blockIdx.x / ntiles;
+    int tile_m, tile_n;
+    gemm_tile_of(blockIdx.x - split * ntiles, p.tiles_m, p.tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- K range of this split -----------------------------------------------------------
@@ -238,84 +199,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #undef LDS_B
     // ---- epilogue: lane owns C[m][n4 .. n4+3] per (i, j) -----------------------------------
     const int g = lane >> 4, lm = lane & 15;
-    TC* __restrict__ C = reinterpret_cast<TC*>(p.C);
-    const T* __restrict__ aux_in = reinterpret_cast<const T*>(p.aux_in);
-    T* __restrict__ aux_out = reinterpret_cast<T*>(p.aux_out);
-    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-    const bool atomic = p.splitk > 1;
-    const bool add_bias = p.bias != nullptr && split == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + lm;
-        if (m >= p.M) continue;
-        long orow = m;
-        if (p.grp_rows > 0) orow = (long)(m / p.grp_rows) * p.grp_stride + p.grp_off + m % p.grp_rows;
-        const long rrow = p.res_period > 0 ? (long)(p.res_off + m % p.res_period) : orow;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n4 = n0 + wn * 64 + j * 16 + 4 * g;
-            if (n4 >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
-            const bool full = p.c_vec_ok && (n4 + 3 < p.N);
-            if (add_bias) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n4 + e < p.N) v[e] += p.bias[n4 + e];
-            }
-            if (p.act == ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (aux_out && n4 + e < p.N) aux_out[orow * p.ld_aux + n4 + e] = from_f32<T>(v[e]);
-                    v[e] = gelu_erf(v[e]);
-                }
-            } else if (p.act == ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (p.act == ACT_DGELU || p.act == ACT_DRELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n4 + e < p.N) {
-                        const float h = to_f32<T>(aux_in[orow * p.ld_aux + n4 + e]);
-                        v[e] *= (p.act == ACT_DGELU) ? gelu_erf_grad(h) : (h > 0.f ? 1.f : 0.f);
-                    }
-                }
-            }
-            if (res) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n4 + e < p.N) v[e] += to_f32<T>(res[rrow * p.ldr + n4 + e]);
-            }
-            TC* dst = C + orow * p.ldc + n4;
-            if (atomic) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n4 + e < p.N) atomicAdd(reinterpret_cast<float*>(dst) + e, v[e]);
-            } else if (full) {
-                if (sizeof(TC) == 4) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    if (p.accumulate) {
-                        const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
-                        o += old;
-                    }
-                    *reinterpret_cast<f32x4*>(dst) = o;
-                } else {
-                    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(dst) = o;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n4 + e < p.N) {
-                        float o = v[e];
-                        if (p.accumulate) o += to_f32<TC>(dst[e]);
-                        dst[e] = from_f32<TC>(o);
-                    }
-                }
-            }
-        }
-    }
+        for (int j = 0; j < 4; ++j)
+            gemm_epilogue4<T, TC>(p, split, m0 + wm * 64 + i * 16 + lm, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j]);
 }
 
 template <typename T, typename TC>
@@ -344,6 +232,11 @@ static void launch_gemm(const GemmParams& p, int transA, int transB, hipStream_t
 
 }  // namespace vitk
 
+namespace vitk {
+bool gemm256_eligible(const GemmParams& p, int transA, int transB);
+void gemm256_launch(const GemmParams& p, int c_dtype, int transA, int transB, hipStream_t stream);
+}  // namespace vitk
+
 using namespace vitk;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -366,14 +259,43 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
     VITK_CHECK_ARG(!(accumulate && c_dtype != VITK_F32), "vitk_gemm: accumulate needs an fp32 output");
     VITK_CHECK_ARG(!(residual && res_period < 0), "vitk_gemm: bad res_period");
     const int esz = dtype == VITK_BF16 ? 2 : 4;
-    const int bk = 128 / esz;
+    const int csz = c_dtype == VITK_BF16 ? 2 : 4;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.act = act;
+    p.aux_in = aux_in; p.aux_out = aux_out; p.ld_aux = ld_aux;
+    p.residual = residual; p.ldr = ldr; p.res_period = res_period; p.res_off = res_off;
+    p.grp_rows = grp_rows; p.grp_stride = grp_stride; p.grp_off = grp_off;
+    p.accumulate = accumulate;
+    p.a_vec_ok = aligned16(A) && (lda * esz) % 16 == 0;
+    p.b_vec_ok = aligned16(B) && (ldb * esz) % 16 == 0;
+    // vector epilogue: 4 consecutive columns of C / aux / residual / bias move as one access
+    const auto al = [](const void* q, int bytes) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % bytes == 0; };
+    p.c_vec_ok = al(C, 4 * csz) && ldc % 4 == 0 && al(bias, 16) && al(aux_in, 4 * esz) && al(aux_out, 4 * esz) &&
+                 al(residual, 4 * esz) && ((!aux_in && !aux_out) || ld_aux % 4 == 0) && (!residual || ldr % 4 == 0);
+    p.c_vec8_ok = p.c_vec_ok && al(C, 16) && (ldc * csz) % 16 == 0 && al(aux_in, 16) && al(aux_out, 16) &&
+                  al(residual, 16) && ((!aux_in && !aux_out) || ld_aux % 8 == 0) && (!residual || ldr % 8 == 0);
+    p.alpha = alpha;
+    const bool linear_f32 = c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out && grp_rows == 0;
+    const bool big = dtype == VITK_BF16 && gemm256_eligible(p, transA, transB);
+    const int tile = big ? 256 : BM;
+    const int bk = big ? 64 : 128 / esz;
     const int ksteps = (K + bk - 1) / bk;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int tiles_m = (M + tile - 1) / tile, tiles_n = (N + tile - 1) / tile;
     if (splitk <= 0) {  // auto: only when the output is fp32 and there is no nonlinear epilogue
         splitk = 1;
-        if (c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out && grp_rows == 0) {
+        if (linear_f32) {
             const int tiles = tiles_m * tiles_n;
-            while (tiles * splitk < 1024 && ksteps / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
+            if (big) {   // one 256-tile workgroup per CU: fill the 256 CUs once, never spill into a second round
+                splitk = 256 / tiles;
+                if (splitk > ksteps / 8) splitk = ksteps / 8;
+                if (splitk > 64) splitk = 64;
+                if (splitk < 1) splitk = 1;
+            } else {
+                while (tiles * splitk < 1024 && ksteps / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
+            }
         }
     }
     splitk = splitk < 1 ? 1 : (splitk > ksteps ? (ksteps > 0 ? ksteps : 1) : splitk);
@@ -394,21 +316,13 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
             }
         }
     }
-    GemmParams p;
-    p.A = A; p.B = B; p.C = C;
-    p.M = M; p.N = N; p.K = K;
-    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.bias = bias; p.act = act;
-    p.aux_in = aux_in; p.aux_out = aux_out; p.ld_aux = ld_aux;
-    p.residual = residual; p.ldr = ldr; p.res_period = res_period; p.res_off = res_off;
-    p.grp_rows = grp_rows; p.grp_stride = grp_stride; p.grp_off = grp_off;
-    p.accumulate = accumulate; p.splitk = splitk;
-    p.a_vec_ok = aligned16(A) && (lda * esz) % 16 == 0;
-    p.b_vec_ok = aligned16(B) && (ldb * esz) % 16 == 0;
-    const int csz = c_dtype == VITK_BF16 ? 2 : 4;
-    p.c_vec_ok = (reinterpret_cast<uintptr_t>(C) % (4 * csz) == 0) && (ldc % 4 == 0);
-    p.alpha = alpha;
+    p.splitk = splitk;
     p.tiles_m = tiles_m; p.tiles_n = tiles_n;
+    if (big) {
+        gemm256_launch(p, c_dtype, transA, transB, stream);
+        VITK_CHECK_LAUNCH("vitk_gemm");
+        return VITK_OK;
+    }
     if (dtype == VITK_BF16) {
         if (c_dtype == VITK_BF16) launch_gemm<__bf16, __bf16>(p, transA, transB, stream);
         else launch_gemm<__bf16, float>(p, transA, transB, stream);
