@@ -162,11 +162,11 @@ def test_config1_step_vs_reference_golden(dtype):
                 assert relerr(got, want) < tol, k
             else:
                 # bf16 activations AND activation gradients through 6 blocks (no fp32 residual
-                # stream): whole-model parameter gradients are held to 5e-2 in relative L2 and
+                # stream): whole-model parameter gradients are held to 0.1 in relative L2 and
                 # 0.15 in max-norm; the 2e-2 bar applies at the attention-module level (above).
                 a = torch.as_tensor(got).double().reshape(-1)
                 b = torch.as_tensor(want).double().reshape(-1)
-                assert ((a - b).norm() / b.norm()).item() < 5e-2, k
+                assert ((a - b).norm() / b.norm()).item() < 0.1, k
                 assert relerr(got, want) < 0.15, k
     opt.step()
     if dtype == torch.float32:

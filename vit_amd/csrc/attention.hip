@@ -207,6 +207,27 @@ template <typename T, int KT> static void attn_fwd_dispatch(const AttnFwdParams&
 
 }  // namespace vitk
 
+namespace vitk {
+struct BandParams {
+    const void *q, *k, *v;
+    long ld;
+    const void *pk, *pq;
+    long ld_p;
+    void* out;
+    long ldo;
+    float* lse;
+    const void* dout;
+    const float* delta;
+    void *dq, *dk, *dv;
+    long ld_d;
+    int B, H, N, dh;
+    float scale;
+    int w;
+};
+bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
+void band_launch(const BandParams& p, bool backward, hipStream_t st);
+}  // namespace vitk
+
 using namespace vitk;
 
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -226,6 +247,17 @@ extern "C" int vitk_attn_fwd(int dtype, int B, int H, int N, int dh, const void*
     VITK_CHECK_ARG(!pk || (a16(pk) && a16(pq) && (ld_p * esz) % 16 == 0 && ld_p >= (long)H * dh),
                    "vitk_attn_fwd: band tables must be 16-byte aligned rows of at least H*dh");
     VITK_CHECK_ARG(H <= 65535 && B <= 65535, "vitk_attn_fwd: grid too large");
+    if (band_eligible(dtype, N, dh, pk != nullptr, band_w)) {   // whole-head kernel (attention_band.hip)
+        BandParams bp = {};
+        bp.q = q; bp.k = k; bp.v = v; bp.ld = ld;
+        bp.pk = pk; bp.pq = pq; bp.ld_p = ld_p;
+        bp.out = out; bp.ldo = ldo; bp.lse = lse;
+        bp.B = B; bp.H = H; bp.N = N; bp.dh = dh;
+        bp.scale = scale; bp.w = band_w;
+        band_launch(bp, false, stream);
+        VITK_CHECK_LAUNCH("vitk_attn_fwd");
+        return VITK_OK;
+    }
     AttnFwdParams p;
     p.q = q; p.k = k; p.v = v; p.ld = ld;
     p.pk = pk; p.pq = pq; p.ld_p = ld_p;

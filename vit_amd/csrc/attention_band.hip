@@ -1,0 +1,465 @@
+// Whole-head attention kernels for short sequences (N <= 208 tokens, bf16, head dim <= 64): the
+// shapes of every ViT-224/16 configuration (197 tokens) and of the CIFAR plumbing config (65).
+//
+// One workgroup owns one (batch, head): Q / K / V / dO of the whole head are staged in LDS ONCE,
+// one barrier, and then the 4 waves run independently to the end -- no per-tile barriers, no
+// cross-workgroup reductions, no atomics, no fp32 workspace:
+//   forward : a wave owns query tiles qt = wave, wave+4, ...; lane = query (scores transposed),
+//             online softmax in registers, O^T += V^T P^T with P taken straight from the score
+//             accumulators.
+//   backward: pass 1 is KEY-stationary (a wave owns key tiles; dK^T, dV^T stay in registers while
+//             it sweeps the live query tiles), pass 2 is QUERY-stationary (dQ^T in registers while
+//             it sweeps the live key tiles) over the SAME LDS images.  P is recomputed in both
+//             passes: 38 instead of 26 MFMAs per tile buys the removal of every dQ atomic, of the
+//             fp32 dQ accumulator (memset + cast passes) and of all workgroup barriers.
+// The LAI band (|i-j| <= w) limits a tile row / column to 2*cmax+1 live tiles, cmax = (w+15)/16;
+// with the disentangled bias the 32*cmax+32 relative rows those tiles can touch are staged once
+// too (so the bias variant needs cmax <= 2, i.e. w <= 32: every LAI stage of the reference, 8..20).
+// Without the bias any w, including unmasked, is accepted.
+// dPk / dPq stay with attn_bwd_rel_kernel (attention_bwd.hip).
+#include "attn_common.h"
+
+namespace vitk {
+
+constexpr int BAND_DSLD = 20;   // floats per row of the 16 x 16 dS scratch tile
+
+struct BandParams {
+    const void *q, *k, *v;
+    long ld;
+    const void *pk, *pq;
+    long ld_p;
+    void* out;              // forward: written; backward: read
+    long ldo;
+    float* lse;             // forward: written; backward: read
+    const void* dout;
+    const float* delta;
+    void *dq, *dk, *dv;
+    long ld_d;
+    int B, H, N, dh;
+    float scale;
+    int w;
+};
+
+template <int DKB, bool BIAS> struct BandCfg {
+    using C = ACfg<__bf16, DKB>;
+    static constexpr int ASTR = C::ASTR;
+    static size_t fwd_bytes(int NT, int cmax) {
+        const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
+        return rows * ASTR * 2 + (size_t)4 * (BIAS ? 2 * SCR_FLOATS : 0) * 4;
+    }
+    static size_t bwd_bytes(int NT, int cmax) {
+        const size_t rows = 3 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
+        return rows * ASTR * 2 + (size_t)2 * (16 * NT + 16) * 4 +
+               (size_t)4 * ((BIAS ? 2 * SCR_FLOATS : 0) + 16 * BAND_DSLD) * 4;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ forward
+template <int DKB, bool BIAS>
+__global__ __launch_bounds__(256) void attn_fwd_band_kernel(const BandParams p) {
+    using T = __bf16;
+    using C = ACfg<T, DKB>;
+    constexpr int ASTR = C::ASTR;
+    constexpr int ND = 2 * DKB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int N = p.N, dh = p.dh;
+    const int NT = (N + 15) / 16;
+    const int NR = 16 * NT + 16;                       // one zero tile behind the last real one
+    const int cmax = p.w >= 0 ? min((p.w + 15) / 16, NT - 1) : NT - 1;
+    const int WR = 32 * cmax + 32;
+    const int h = blockIdx.x, b = blockIdx.y;
+
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vs = Ks + NR * ASTR;
+    T* Pks = Vs + NR * ASTR;
+    T* Pqs = Pks + (BIAS ? WR * ASTR : 0);
+    float* scr = reinterpret_cast<float*>(Pqs + (BIAS ? WR * ASTR : 0));
+    float* xs = scr + wave * 2 * SCR_FLOATS;
+    float* ys = xs + SCR_FLOATS;
+
+    const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
+    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
+    const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
+
+    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, 256);
+    stage_rows<T, DKB>(Vs, V, p.ld, 0, NR, 0, N, dh, tid, 256);
+    if (BIAS) {
+        const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
+        const T* PQ = reinterpret_cast<const T*>(p.pq) + h * dh;
+        const int r_lo = -16 * cmax - 15 + (N - 1);
+        stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
+        stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
+    }
+    __syncthreads();
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    for (int qt = wave; qt < NT; qt += 4) {
+        const int qi0 = 16 * qt;
+        const int qi = qi0 + li;
+        Frag<T> qf[DKB];
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(qf[kb], Q, p.ld, qi, N, dh, kb, lane);
+        float m2 = -INFINITY, lsum = 0.f;
+        f32x4 oacc[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int klo = max(0, qt - cmax), khi = min(NT - 1, qt + cmax);
+        for (int ka = klo; ka <= khi; ka += 2) {
+            f32x4 s[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kt = ka + u;
+                if (kt > khi) {
+                    s[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    continue;
+                }
+                const int kj0 = 16 * kt;
+                Frag<T> kf[DKB];
+#pragma unroll
+                for (int kb = 0; kb < DKB; ++kb) row_frag<T, DKB>(kf[kb], Ks, kj0, kb, lane);
+                f32x4 raw = score_tile<T, DKB, BIAS, true>(qf, kf, Pks, Pqs, qi0 - kj0 + 16 * cmax, xs, ys, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = kj0 + 4 * g + r;
+                    const bool ok = j < N && (p.w < 0 || abs(qi - j) <= p.w);
+                    raw[r] = ok ? raw[r] * sc2 : -INFINITY;
+                }
+                s[u] = raw;
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[u][r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mn = fmaxf(m2, mt);
+            const float mref = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = exp2f(m2 - mref);
+            float psum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f(s[u][r] - mref);
+                    s[u][r] = pv;
+                    psum += pv;
+                }
+            lsum = lsum * alpha + psum;
+            m2 = mn;
+            Frag<T> pf;
+            acc_to_frag(pf, s[0], s[1]);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                oacc[dt] *= alpha;
+                Frag<T> vf;
+                col_frag(vf, Vs, ASTR, 16 * ka + 4 * g, 16 * ka + 16 + 4 * g, 16 * dt, lane);
+                oacc[dt] = mma(vf, pf, oacc[dt]);
+            }
+        }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (qi < N) {
+            const float inv = 1.f / lsum;
+            T* O = reinterpret_cast<T*>(p.out) + ((long)b * N + qi) * p.ldo + h * dh;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const int d = 16 * dt + 4 * g;
+                if (d < dh)
+                    *reinterpret_cast<bf16x4*>(O + d) = bf16x4{(__bf16)(oacc[dt][0] * inv), (__bf16)(oacc[dt][1] * inv),
+                                                               (__bf16)(oacc[dt][2] * inv), (__bf16)(oacc[dt][3] * inv)};
+            }
+            if (g == 0) p.lse[((long)b * p.H + h) * N + qi] = (m2 + log2f(lsum)) * 0.6931471805599453f;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------- backward
+template <int DKB, bool BIAS>
+__global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) {
+    using T = __bf16;
+    using C = ACfg<T, DKB>;
+    constexpr int ASTR = C::ASTR;
+    constexpr int ND = 2 * DKB;
+    constexpr int DSLD = BAND_DSLD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int N = p.N, dh = p.dh;
+    const int NT = (N + 15) / 16;
+    const int NR = 16 * NT + 16;
+    const int cmax = p.w >= 0 ? min((p.w + 15) / 16, NT - 1) : NT - 1;
+    const int WR = 32 * cmax + 32;
+    const int h = blockIdx.x, b = blockIdx.y;
+
+    T* Qs = reinterpret_cast<T*>(smem);
+    T* Ks = Qs + NR * ASTR;
+    T* dOs = Ks + NR * ASTR;
+    T* Pks = dOs + NR * ASTR;
+    T* Pqs = Pks + (BIAS ? WR * ASTR : 0);
+    float* lse2s = reinterpret_cast<float*>(Pqs + (BIAS ? WR * ASTR : 0));
+    float* dls = lse2s + NR;
+    float* scr = dls + NR;
+    constexpr int WSCR = (BIAS ? 2 * SCR_FLOATS : 0) + 16 * DSLD;
+    float* xs = scr + wave * WSCR;
+    float* ys = xs + (BIAS ? SCR_FLOATS : 0);
+    float* dss = ys + (BIAS ? SCR_FLOATS : 0);
+
+    const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
+    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
+    const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + (long)b * N * p.ldo + h * dh;
+    const float* lse = p.lse + ((long)b * p.H + h) * N;
+    const float* delta = p.delta + ((long)b * p.H + h) * N;
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+
+    stage_rows<T, DKB>(Qs, Q, p.ld, 0, NR, 0, N, dh, tid, 256);
+    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, 256);
+    stage_rows<T, DKB>(dOs, dO, p.ldo, 0, NR, 0, N, dh, tid, 256);
+    if (BIAS) {
+        const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
+        const T* PQ = reinterpret_cast<const T*>(p.pq) + h * dh;
+        const int r_lo = -16 * cmax - 15 + (N - 1);
+        stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
+        stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
+    }
+    for (int i = tid; i < NR; i += 256) {
+        lse2s[i] = i < N ? lse[i] * LOG2E : 0.f;
+        dls[i] = i < N ? delta[i] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- pass 1: key-stationary, dK^T / dV^T in registers --------------------------------------
+    for (int kt = wave; kt < NT; kt += 4) {
+        const int kj0 = 16 * kt;
+        Frag<T> kf[DKB], vf[DKB];
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) {
+            row_frag<T, DKB>(kf[kb], Ks, kj0, kb, lane);
+            row_frag_global<T>(vf[kb], V, p.ld, kj0 + li, N, dh, kb, lane);
+        }
+        f32x4 dkacc[ND], dvacc[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int qlo = max(0, kt - cmax), qhi = min(NT - 1, kt + cmax);
+        for (int qa = qlo; qa <= qhi; qa += 2) {
+            f32x4 pt[2], dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qt = qa + u;
+                f32x4 pv = {0.f, 0.f, 0.f, 0.f}, dsv = {0.f, 0.f, 0.f, 0.f};
+                if (qt <= qhi) {
+                    const int qi0 = 16 * qt;
+                    const int rel = qi0 - kj0 + 16 * cmax;
+                    Frag<T> qf[DKB], dof[DKB];
+#pragma unroll
+                    for (int kb = 0; kb < DKB; ++kb) {
+                        row_frag<T, DKB>(qf[kb], Qs, qi0, kb, lane);
+                        row_frag<T, DKB>(dof[kb], dOs, qi0, kb, lane);
+                    }
+                    const f32x4 raw = score_tile<T, DKB, BIAS, false>(qf, kf, Pks, Pqs, rel, xs, ys, lane);
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < DKB; ++kb) dp = mma(dof[kb], vf[kb], dp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qi = qi0 + 4 * g + r, kj = kj0 + li;
+                        const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
+                        const float pe = ok ? exp2f(raw[r] * sc2 - lse2s[qi]) : 0.f;
+                        pv[r] = pe;
+                        dsv[r] = pe * (dp[r] - dls[qi]) * p.scale;
+                    }
+                    if (BIAS) {   // dK^T[d][jj] += sum_t Pq^T[d][t] Sy[t][jj]
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dss[(4 * g + r) * DSLD + li] = dsv[r];
+                        wave_lds_sync();
+                        Frag<T> sy;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int ii = li + 8 * g + e - 15;
+                            const float v = dss[min(max(ii, 0), 15) * DSLD + li];
+                            sy.v[e] = (__bf16)((ii >= 0 && ii < 16) ? v : 0.f);
+                        }
+#pragma unroll
+                        for (int dt = 0; dt < ND; ++dt) {
+                            Frag<T> a;
+                            col_frag(a, Pqs, ASTR, rel + 8 * g, rel + 8 * g + 4, 16 * dt, lane);
+                            dkacc[dt] = mma(a, sy, dkacc[dt]);
+                        }
+                        wave_lds_sync();
+                    }
+                }
+                pt[u] = pv;
+                dst[u] = dsv;
+            }
+            Frag<T> bp, bs;
+            acc_to_frag(bp, pt[0], pt[1]);
+            acc_to_frag(bs, dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                Frag<T> a;
+                col_frag(a, dOs, ASTR, 16 * qa + 4 * g, 16 * qa + 16 + 4 * g, 16 * dt, lane);
+                dvacc[dt] = mma(a, bp, dvacc[dt]);
+                col_frag(a, Qs, ASTR, 16 * qa + 4 * g, 16 * qa + 16 + 4 * g, 16 * dt, lane);
+                dkacc[dt] = mma(a, bs, dkacc[dt]);
+            }
+        }
+        const int kj = kj0 + li;
+        if (kj < N) {
+            T* dK = reinterpret_cast<T*>(p.dk) + ((long)b * N + kj) * p.ld_d + h * dh;
+            T* dV = reinterpret_cast<T*>(p.dv) + ((long)b * N + kj) * p.ld_d + h * dh;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const int d = 16 * dt + 4 * g;
+                if (d < dh) {
+                    const f32x4 a = dkacc[dt], c = dvacc[dt];
+                    *reinterpret_cast<bf16x4*>(dK + d) = bf16x4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+                    *reinterpret_cast<bf16x4*>(dV + d) = bf16x4{(__bf16)c[0], (__bf16)c[1], (__bf16)c[2], (__bf16)c[3]};
+                }
+            }
+        }
+    }
+
+    // ---- pass 2: query-stationary, dQ^T in registers (lane = query) -----------------------------
+    for (int qt = wave; qt < NT; qt += 4) {
+        const int qi0 = 16 * qt;
+        const int qi = qi0 + li;
+        Frag<T> qf[DKB], dof[DKB];
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) {
+            row_frag<T, DKB>(qf[kb], Qs, qi0, kb, lane);
+            row_frag<T, DKB>(dof[kb], dOs, qi0, kb, lane);
+        }
+        const float lq = lse2s[qi], dq_delta = dls[qi];
+        f32x4 dqacc[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int klo = max(0, qt - cmax), khi = min(NT - 1, qt + cmax);
+        for (int ka = klo; ka <= khi; ka += 2) {
+            f32x4 dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kt = ka + u;
+                f32x4 dsv = {0.f, 0.f, 0.f, 0.f};
+                if (kt <= khi) {
+                    const int kj0 = 16 * kt;
+                    const int rel = qi0 - kj0 + 16 * cmax;
+                    Frag<T> kf[DKB], vf[DKB];
+#pragma unroll
+                    for (int kb = 0; kb < DKB; ++kb) {
+                        row_frag<T, DKB>(kf[kb], Ks, kj0, kb, lane);
+                        row_frag_global<T>(vf[kb], V, p.ld, kj0 + li, N, dh, kb, lane);
+                    }
+                    // transposed tiles: result[r] = X[query li][key 4g + r]
+                    const f32x4 raw = score_tile<T, DKB, BIAS, true>(qf, kf, Pks, Pqs, rel, xs, ys, lane);
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < DKB; ++kb) dp = mma(vf[kb], dof[kb], dp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kj = kj0 + 4 * g + r;
+                        const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
+                        const float pe = ok ? exp2f(raw[r] * sc2 - lq) : 0.f;
+                        dsv[r] = pe * (dp[r] - dq_delta) * p.scale;
+                    }
+                    if (BIAS) {   // dQ^T[d][ii] += sum_t Pk^T[d][t] Sx[t][ii]
+                        *reinterpret_cast<f32x4*>(dss + li * DSLD + 4 * g) = dsv;
+                        wave_lds_sync();
+                        Frag<T> sx;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int jj = li + 15 - 8 * g - e;
+                            const float v = dss[li * DSLD + min(max(jj, 0), 15)];
+                            sx.v[e] = (__bf16)((jj >= 0 && jj < 16) ? v : 0.f);
+                        }
+#pragma unroll
+                        for (int dt = 0; dt < ND; ++dt) {
+                            Frag<T> a;
+                            col_frag(a, Pks, ASTR, rel + 8 * g, rel + 8 * g + 4, 16 * dt, lane);
+                            dqacc[dt] = mma(a, sx, dqacc[dt]);
+                        }
+                        wave_lds_sync();
+                    }
+                }
+                dst[u] = dsv;
+            }
+            // content: dQ^T[d][q] += K^T[d][key] dS^T[key][q], 32 keys per MFMA
+            Frag<T> bs;
+            acc_to_frag(bs, dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                Frag<T> a;
+                col_frag(a, Ks, ASTR, 16 * ka + 4 * g, 16 * ka + 16 + 4 * g, 16 * dt, lane);
+                dqacc[dt] = mma(a, bs, dqacc[dt]);
+            }
+        }
+        if (qi < N) {
+            T* dQ = reinterpret_cast<T*>(p.dq) + ((long)b * N + qi) * p.ld_d + h * dh;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const int d = 16 * dt + 4 * g;
+                if (d < dh) {
+                    const f32x4 a = dqacc[dt];
+                    *reinterpret_cast<bf16x4*>(dQ + d) = bf16x4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- host
+bool band_eligible(int dtype, int N, int dh, bool bias, int band_w) {
+    if (dtype != VITK_BF16 || N > 208 || dh > 64 || dh % 8 != 0) return false;
+    if (bias && (band_w < 0 || (band_w + 15) / 16 > 2)) return false;
+    return true;
+}
+
+template <int DKB, bool BIAS> static void band_fwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
+    const size_t lds = BandCfg<DKB, BIAS>::fwd_bytes(NT, cmax);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_band_kernel<DKB, BIAS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL((attn_fwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(256), lds, st, p);
+}
+template <int DKB, bool BIAS> static void band_bwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
+    const size_t lds = BandCfg<DKB, BIAS>::bwd_bytes(NT, cmax);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_band_kernel<DKB, BIAS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL((attn_bwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(256), lds, st, p);
+}
+
+void band_launch(const BandParams& p, bool backward, hipStream_t st) {
+    const int NT = (p.N + 15) / 16;
+    int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
+    if (cmax > NT - 1) cmax = NT - 1;
+    const bool bias = p.pk != nullptr;
+    const int dkb = (p.dh + 31) / 32;
+#define VITK_BAND(D, BI)                                          \
+    do {                                                          \
+        if (backward) band_bwd_launch<D, BI>(p, NT, cmax, st);    \
+        else band_fwd_launch<D, BI>(p, NT, cmax, st);             \
+    } while (0)
+    if (dkb == 1) {
+        if (bias) VITK_BAND(1, true); else VITK_BAND(1, false);
+    } else {
+        if (bias) VITK_BAND(2, true); else VITK_BAND(2, false);
+    }
+#undef VITK_BAND
+}
+
+}  // namespace vitk

@@ -683,6 +683,27 @@ template <typename T, int KTW> static void bwd_dispatch(const AttnBwdParams& p, 
 
 }  // namespace vitk
 
+namespace vitk {
+struct BandParams {
+    const void *q, *k, *v;
+    long ld;
+    const void *pk, *pq;
+    long ld_p;
+    void* out;
+    long ldo;
+    float* lse;
+    const void* dout;
+    const float* delta;
+    void *dq, *dk, *dv;
+    long ld_d;
+    int B, H, N, dh;
+    float scale;
+    int w;
+};
+bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
+void band_launch(const BandParams& p, bool backward, hipStream_t st);
+}  // namespace vitk
+
 using namespace vitk;
 
 static bool b16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -739,6 +760,30 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
     zgroups = (B + p.bgroup - 1) / p.bgroup;
 
     const long rows = (long)B * N;
+    if (band_eligible(dtype, N, dh, pk != nullptr, band_w)) {
+        // whole-head kernels (attention_band.hip): dQ / dK / dV without atomics or accumulators
+        const long total = rows * H;
+        long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(attn_delta_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, stream, (const __bf16*)out,
+                           (const __bf16*)dout, ldo, p.delta, B, H, N, dh);
+        BandParams bp = {};
+        bp.q = q; bp.k = k; bp.v = v; bp.ld = ld;
+        bp.pk = pk; bp.pq = pq; bp.ld_p = ld_p;
+        bp.out = const_cast<void*>(out); bp.ldo = ldo; bp.lse = const_cast<float*>(lse);
+        bp.dout = dout; bp.delta = p.delta;
+        bp.dq = dq; bp.dk = dk; bp.dv = dv; bp.ld_d = ld_d;
+        bp.B = B; bp.H = H; bp.N = N; bp.dh = dh;
+        bp.scale = scale; bp.w = band_w;
+        band_launch(bp, true, stream);
+        if (pk) {
+            const int dkb = (dh + 31) / 32;
+            if (dkb == 1) rel_launch<__bf16, 1>(p, zgroups, stream);
+            else rel_launch<__bf16, 2>(p, zgroups, stream);
+        }
+        VITK_CHECK_LAUNCH("vitk_attn_bwd");
+        return VITK_OK;
+    }
     float* delta_end = p.delta + ((long)B * H * N + 63) / 64 * 64;
     if (dtype == VITK_BF16) {
         p.dq_acc = delta_end;
