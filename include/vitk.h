@@ -107,6 +107,26 @@ int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void* q, const v
                   void* dq, void* dk, void* dv, long ld_d, float* dpk, float* dpq, long ld_dp,
                   void* workspace, void* stream);
 
+/* FAVOR+ (Performer) attention: feature maps + linear-attention contraction + normaliser, between
+ * the qkv projection and the output projection.  Replaces PerformerAttention.forward :36-59 with
+ * softmax_kernel_transformation :69-91 / relu_kernel_transformation :93-101
+ * (timm_classes/timm_vision_performer.py) and MultiheadAttentionPerformer.forward :283-313 with
+ * :320-352 (model.py), quirks included: diag = plain sum of the features / 2 * dh^-1/2, the key
+ * stabiliser is the max over the WHOLE [B,L,H,m] tensor, eps inside the ratio.
+ * kind 0 = softmax kernel (eps 1e-6), 1 = relu kernel (eps 1e-3); ratio = m^-1/4 (timm variant,
+ * relu of model.py) or m^-1/2 (softmax of model.py).  w [m][dh] in T, contiguous, m <= 256, dh <= 64.
+ * q / k / v / out addressing as vitk_attn_fwd.  `workspace` (vitk_favor_workspace_bytes) receives
+ * KV, ksum and the key max / argmax in the forward and is read by the backward of the same step
+ * (which also routes the gradient through both maxima). */
+long vitk_favor_workspace_bytes(int dtype, int B, int H, int dh, int m);
+int vitk_favor_fwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                   const void* v, long ld, const void* w, float ratio, float eps, void* out, long ldo,
+                   void* workspace, void* stream);
+int vitk_favor_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                   const void* v, long ld, const void* w, float ratio, float eps, const void* out,
+                   const void* dout, long ldo, void* dq, void* dk, void* dv, long ld_d, void* workspace,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

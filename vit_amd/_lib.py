@@ -40,6 +40,11 @@ _SIGNATURES = {
                        c_float, c_int, c_vp, c_vp, c_long, c_vp,
                        c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_vp], c_int),
     'vitk_attn_bwd_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),
+    'vitk_favor_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),
+    'vitk_favor_fwd': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_long, c_vp,
+                        c_float, c_float, c_vp, c_long, c_vp, c_vp], c_int),
+    'vitk_favor_bwd': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_long, c_vp,
+                        c_float, c_float, c_vp, c_vp, c_long, c_vp, c_vp, c_vp, c_long, c_vp, c_vp], c_int),
 }
 
 

@@ -45,6 +45,11 @@ __device__ __forceinline__ void frag_zero(Frag<float>& f) {
     for (int e = 0; e < 8; ++e) f.v[e] = 0.0f;
 }
 
+__device__ __forceinline__ void frag_set_f(Frag<__bf16>& f, int e, float v) { f.v[e] = (__bf16)v; }
+__device__ __forceinline__ void frag_set_f(Frag<float>& f, int e, float v) { f.v[e] = v; }
+__device__ __forceinline__ float frag_get_f(const Frag<__bf16>& f, int e) { return (float)f.v[e]; }
+__device__ __forceinline__ float frag_get_f(const Frag<float>& f, int e) { return f.v[e]; }
+
 // D(16x16) += A(16x32) * B(32x16); a = A rows on lanes, b = B columns on lanes.
 __device__ __forceinline__ f32x4 mma(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);

@@ -1,2 +1,863 @@
-// placeholder, replaced below
-#include "common.h"
+// FAVOR+ (Performer) random-feature attention: feature maps and the linear-attention contraction,
+// forward and backward, as MFMA products with wave-reduced normalisers.
+//
+// Replaces PerformerAttention.forward / softmax_kernel_transformation / relu_kernel_transformation
+// (timm_classes/timm_vision_performer.py:26-101) and MultiheadAttentionPerformer.forward
+// (model.py:257-352) between the qkv projection and the output projection, quirk for quirk:
+//   dd   = data . w^T                      (data is NOT pre-scaled by dh^-1/4)
+//   diag = (sum_d data_d) / 2 * dh^-1/2    (plain sum: the reference overwrites its square, :76-78)
+//   q'   = ratio * (exp(dd - diag - max_m dd) + eps)                       per row
+//   k'   = ratio * (exp(dd - diag - max over the WHOLE [B,L,H,m] tensor) + eps)
+//   relu : relu(ratio * dd) + eps
+//   KV[b,h] = sum_l k'_l^T v_l,  ksum[b,h] = sum_l k'_l,  out_l = (q'_l KV) / (q'_l . ksum)
+// and the gradients of all of it, including the gradient through BOTH stabilising maxima (the
+// argmax element receives minus the sum of the row's / the tensor's exp-gradients).
+//
+// q, k, v, out, dout, dq, dk, dv: element (b, l, h, d) at ((b*L + l) * ld + h*dh + d) -- views into
+// packed [B*L, 3D] / [B*L, D] buffers, as for the softmax attention kernels.
+// One workgroup = one (b, h) for every kernel that reduces over l; its 4 waves split l.
+//
+// Orientation: most products run with the token l on the MFMA LANE (dd^T[m][l] = w . data^T), so
+// per-token scalars (row max, diag, den) are lane-local and the feature tiles are directly the B
+// operand of the next product (sum over m).  Products that sum over l (KV, dKV) recompute dd with
+// l in the accumulator ROWS and take V / dO through a wave-private LDS image (hardware transposed
+// read for bf16).
+#include "attn_common.h"
+
+namespace vitk {
+
+enum { FAVOR_SOFTMAX = 0, FAVOR_RELU = 1 };
+
+struct FavorParams {
+    const void *q, *k, *v;
+    long ld;
+    const void* w;          // [m][dh], T
+    void* kvt;              // [B][H][dh][mp]  T   (KV transposed: rows d)
+    void* kv;               // [B][H][mp][dhp] T   (KV: rows m)
+    float* ksum;            // [B][H][mp]
+    unsigned long long* kmax;   // packed (ordered float bits << 32 | flat index)
+    void* out;
+    long ldo;
+    const void* dout;
+    float* dkvt;            // [B][H][dh][mp]  fp32 (backward: d KV transposed)
+    float* dksum;           // [B][H][mp]
+    void *dkvt_t, *dkv_t;   // T copies of dKV in both layouts (written by the q-side backward)
+    float *kv32, *dkv32;    // fp32 [B][H][mp][dhp] copies: the two cancelling products of the backward use them
+    float* esum;            // global sum of the key-side exp gradients
+    void *dq, *dk, *dv;
+    long ld_d;
+    int B, H, L, dh, m, mp, dhp;
+    int kind;
+    float ratio, eps, diag_c;
+};
+
+__device__ __forceinline__ unsigned int ordered_bits(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unordered_bits(unsigned int k) {
+    const unsigned int u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, const f32x4& v) {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+
+// Fragment whose 8 k-slots are two runs of 4 consecutive elements (p0[0..3], p1[0..3]): the k order
+// of acc_to_frag (tile a rows 4g..4g+3, tile b rows 4g..4g+3).
+template <typename T> __device__ __forceinline__ void frag_load_split(Frag<T>& f, const T* p0, const T* p1, bool ok1) {
+    const f32x4 a = load4<T>(p0);
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (ok1) b = load4<T>(p1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        frag_set_f(f, e, a[e]);
+        frag_set_f(f, 4 + e, b[e]);
+    }
+}
+
+// bf16 hi / lo split of fp32 values: x ~ hi + lo to ~16 mantissa bits.  The backward's two
+// cancelling products (KV . dnum + dden ksum, dKV . v + dksum) run as hi.hi + hi.lo + lo.hi so the
+// bf16 path keeps fp32-like accuracy exactly where rounding would be amplified.
+__device__ __forceinline__ void split_set(Frag<__bf16>& hi, Frag<__bf16>& lo, int e, float x) {
+    const __bf16 h = (__bf16)x;
+    hi.v[e] = h;
+    lo.v[e] = (__bf16)(x - (float)h);
+}
+__device__ __forceinline__ void acc_to_frag_hilo(Frag<__bf16>& hi, Frag<__bf16>& lo, const f32x4& a, const f32x4& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        split_set(hi, lo, e, a[e]);
+        split_set(hi, lo, 4 + e, b[e]);
+    }
+}
+
+// feature value and its derivative factor d val / d dd (without the max-routing term)
+__device__ __forceinline__ float feat(int kind, float dd, float diag, float stab, float ratio, float eps) {
+    if (kind == FAVOR_SOFTMAX) return ratio * (expf(dd - diag - stab) + eps);
+    return fmaxf(ratio * dd, 0.f) + eps;
+}
+__device__ __forceinline__ float feat_grad(int kind, float dd, float diag, float stab, float ratio) {
+    if (kind == FAVOR_SOFTMAX) return ratio * expf(dd - diag - stab);
+    return dd > 0.f ? ratio : 0.f;
+}
+
+// dd^T tiles for the 16 tokens of a fragment set: acc[mt][r] = dd[token li][feature 16mt + 4g + r]
+template <typename T, int DKB, int MT>
+__device__ __forceinline__ void ddT_tiles(f32x4 (&acc)[MT], const Frag<T> (&xf)[DKB], const T* __restrict__ w, int m,
+                                          int dh, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) {
+            Frag<T> wf;
+            row_frag_global<T>(wf, w, dh, 16 * mt + li, m, dh, kb, lane);
+            s = mma(wf, xf[kb], s);
+        }
+        acc[mt] = s;
+    }
+}
+
+// per-token sum of the data row (lane = token): sum of the lane's fragment elements over g
+template <typename T, int DKB> __device__ __forceinline__ float row_sum(const Frag<T> (&xf)[DKB]) {
+    float s = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < DKB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += frag_get_f(xf[kb], e);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+}
+
+// ------------------------------------------------------------------ global key max (+ argmax)
+template <typename T, int DKB, int MT>
+__global__ __launch_bounds__(256) void favor_kmax_kernel(const FavorParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int L = p.L, dh = p.dh, m = p.m;
+    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
+    const T* W = reinterpret_cast<const T*>(p.w);
+    unsigned long long best = 0ull;
+    for (int l0 = 16 * wave; l0 < L; l0 += 64) {
+        Frag<T> xf[DKB];
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(xf[kb], K, p.ld, l0 + li, L, dh, kb, lane);
+        f32x4 dd[MT];
+        ddT_tiles<T, DKB, MT>(dd, xf, W, m, dh, lane);
+        const int l = l0 + li;
+        if (l < L) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mi = 16 * mt + 4 * g + r;
+                    if (mi < m) {
+                        const unsigned long long idx = (((unsigned long long)b * L + l) * p.H + h) * m + mi;
+                        // ties: the smaller flat index wins (stored inverted)
+                        const unsigned long long key = ((unsigned long long)ordered_bits(dd[mt][r]) << 32) |
+                                                       (0xffffffffull - idx);
+                        best = key > best ? key : best;
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if (lane == 0) atomicMax(p.kmax, best);
+}
+
+// ------------------------------------------------------------------ KV, ksum
+// grid (m chunks of 16*MTC features, H, B).  dd is computed with tokens in the accumulator rows:
+// acc[r] = dd[token 4g + r][feature li]; k' tiles of two token tiles are the B operand of
+// KV^T[d][m] += V^T[d][l] k'[l][m] (A = transposed read of the wave's V image).
+template <typename T, int DKB, int MTC>
+__global__ __launch_bounds__(256) void favor_kv_kernel(const FavorParams p) {
+    using C = ACfg<T, DKB>;
+    constexpr int ASTR = C::ASTR;
+    constexpr int ND = 2 * DKB;
+    constexpr int RLD = 16 * MTC + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int mc0 = blockIdx.x * 16 * MTC, h = blockIdx.y, b = blockIdx.z;
+    const int L = p.L, dh = p.dh, m = p.m;
+    T* Vw = reinterpret_cast<T*>(smem) + wave * 32 * ASTR;
+    float* red = reinterpret_cast<float*>(reinterpret_cast<T*>(smem) + 4 * 32 * ASTR);   // [32*DKB][RLD] + ksum[16*MTC]
+    float* ksr = red + 32 * DKB * RLD;
+    for (int i = tid; i < 32 * DKB * RLD + 16 * MTC; i += 256) red[i] = 0.f;
+    __syncthreads();
+
+    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
+    const T* V = reinterpret_cast<const T*>(p.v) + (long)b * L * p.ld + h * dh;
+    const T* W = reinterpret_cast<const T*>(p.w);
+    float stab = 0.f;
+    if (p.kind == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(*p.kmax >> 32));
+
+    Frag<T> ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) frag_set_f(ones, e, 1.f);
+    Frag<T> wf[MTC][DKB];
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt)
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(wf[mt][kb], W, dh, mc0 + 16 * mt + li, m, dh, kb, lane);
+
+    f32x4 acc[ND][MTC];
+    float ks[MTC];
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+        ks[mt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) acc[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int l0 = 32 * wave; l0 < L; l0 += 128) {
+        stage_rows<T, DKB>(Vw, V, p.ld, l0, 32, 0, L, dh, lane, 64);
+        f32x4 kp[2][MTC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Frag<T> xf[DKB];
+            f32x4 dg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < DKB; ++kb) {
+                row_frag_global<T>(xf[kb], K, p.ld, l0 + 16 * u + li, L, dh, kb, lane);
+                dg = mma(xf[kb], ones, dg);            // row sums of K: dg[r] = sum_d K[4g+r][d]
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTC; ++mt) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < DKB; ++kb) s = mma(xf[kb], wf[mt][kb], s);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (l0 + 16 * u + 4 * g + r < L) && (mc0 + 16 * mt + li < m);
+                    const float v = ok ? feat(p.kind, s[r], dg[r] * p.diag_c, stab, p.ratio, p.eps) : 0.f;
+                    kp[u][mt][r] = v;
+                    ks[mt] += v;
+                }
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) {
+            Frag<T> bf;
+            acc_to_frag(bf, kp[0][mt], kp[1][mt]);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                Frag<T> a;
+                col_frag(a, Vw, ASTR, 4 * g, 16 + 4 * g, 16 * dt, lane);
+                acc[dt][mt] = mma(a, bf, acc[dt][mt]);
+            }
+        }
+        wave_lds_sync();
+    }
+    // reduce the 4 waves: acc[dt][mt][r] = KV^T[d = 16dt+4g+r][feature 16mt+li]
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+        float s = ks[mt];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (g == 0) atomicAdd(&ksr[16 * mt + li], s);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li], acc[dt][mt][r]);
+    }
+    __syncthreads();
+    T* KVT = reinterpret_cast<T*>(p.kvt) + ((long)b * p.H + h) * dh * p.mp;
+    T* KV = reinterpret_cast<T*>(p.kv) + ((long)b * p.H + h) * p.mp * p.dhp;
+    float* KS = p.ksum + ((long)b * p.H + h) * p.mp;
+    for (int i = tid; i < p.dhp * 16 * MTC; i += 256) {
+        const int d = i / (16 * MTC), mm = i - d * 16 * MTC;
+        const float v = d < dh ? red[d * RLD + mm] : 0.f;
+        if (d < dh) KVT[(long)d * p.mp + mc0 + mm] = from_f32<T>(v);
+        KV[(long)(mc0 + mm) * p.dhp + d] = from_f32<T>(v);
+        p.kv32[(((long)b * p.H + h) * p.mp + mc0 + mm) * p.dhp + d] = v;
+    }
+    for (int i = tid; i < 16 * MTC; i += 256) KS[mc0 + i] = ksr[i];
+}
+
+// ------------------------------------------------------------------ out = (q' KV) / (q' . ksum)
+// grid (ceil(L / 64), H, B); a wave owns 16 tokens, lane = token.
+template <typename T, int DKB, int MT>
+__global__ __launch_bounds__(256) void favor_out_kernel(const FavorParams p) {
+    constexpr int ND = 2 * DKB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int l0 = blockIdx.x * 64 + 16 * wave, h = blockIdx.y, b = blockIdx.z;
+    const int L = p.L, dh = p.dh, m = p.m;
+    if (l0 >= L) return;
+    const int l = l0 + li;
+    const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * L * p.ld + h * dh;
+    const T* W = reinterpret_cast<const T*>(p.w);
+    const T* KVT = reinterpret_cast<const T*>(p.kvt) + ((long)b * p.H + h) * dh * p.mp;
+    const float* KS = p.ksum + ((long)b * p.H + h) * p.mp;
+
+    Frag<T> xf[DKB];
+#pragma unroll
+    for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(xf[kb], Q, p.ld, l, L, dh, kb, lane);
+    f32x4 dd[MT];
+    ddT_tiles<T, DKB, MT>(dd, xf, W, m, dh, lane);
+    const float diag = row_sum<T, DKB>(xf) * p.diag_c;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (16 * mt + 4 * g + r < m) mx = fmaxf(mx, dd[mt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 ksv = *reinterpret_cast<const f32x4*>(KS + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = 16 * mt + 4 * g + r < m;
+            const float v = ok ? feat(p.kind, dd[mt][r], diag, mx, p.ratio, p.eps) : 0.f;
+            dd[mt][r] = v;
+            den += v * ksv[r];
+        }
+    }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.f / den;
+    T* O = reinterpret_cast<T*>(p.out) + ((long)b * L + l) * p.ldo + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        f32x4 num = {0.f, 0.f, 0.f, 0.f};
+        const int d = 16 * dt + li;              // A row: KV^T[d][.]
+#pragma unroll
+        for (int mb = 0; mb < (MT + 1) / 2; ++mb) {
+            Frag<T> a, bq;
+            const bool has2 = 2 * mb + 1 < MT;
+            if (d < dh) frag_load_split<T>(a, KVT + (long)d * p.mp + 32 * mb + 4 * g, KVT + (long)d * p.mp + 32 * mb + 16 + 4 * g, has2);
+            else frag_zero(a);
+            acc_to_frag(bq, dd[2 * mb], has2 ? dd[2 * mb + 1] : f32x4{0.f, 0.f, 0.f, 0.f});
+            num = mma(a, bq, num);
+        }
+        const int dd0 = 16 * dt + 4 * g;
+        if (l < L && dd0 < dh) store4<T>(O + dd0, num * inv);
+    }
+}
+
+// ------------------------------------------------------------------ backward, query side
+// One workgroup per (b, h); waves split the tokens in blocks of 16.
+//   given dout: dnum = dout / den, dden = -(dout . out) / den
+//   dq'[l][m] = KV[m] . dnum[l] + dden[l] ksum[m];   e = dq' * d feat / d dd
+//   d dd = e - [m = argmax] sum_m e (softmax kernel);  d diag = -sum_m e
+//   dQ[l] = d dd[l] . w + d diag * diag_c
+//   dKV^T[d][m] += dO^T[d][l] q'[l][m] / den[l];  dksum[m] += dden[l] q'[l][m]
+template <typename T, int DKB, int MT>
+__global__ __launch_bounds__(256) void favor_bwd_q_kernel(const FavorParams p) {
+    using C = ACfg<T, DKB>;
+    constexpr int ASTR = C::ASTR;
+    constexpr int ND = 2 * DKB;
+    constexpr int MP = 16 * MT;
+    constexpr int RLD = MP + 4;
+    constexpr int WTLD = MP + 8;                  // elements per row of the transposed w image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int L = p.L, dh = p.dh, m = p.m;
+    T* wT = reinterpret_cast<T*>(smem);                          // [32*DKB][WTLD]: w^T, rows d
+    T* dOw = wT + 32 * DKB * WTLD + wave * 16 * ASTR;            // wave-private dO image (16 rows)
+    float* red = reinterpret_cast<float*>(wT + 32 * DKB * WTLD + 4 * 16 * ASTR);   // [32*DKB][RLD]
+    float* dksr = red + 32 * DKB * RLD;                          // [MP]
+    float* rowv = dksr + MP + wave * 64;                         // per wave: inv_den[16], dden[16], mx[16], diag[16]
+
+    const T* W = reinterpret_cast<const T*>(p.w);
+    for (int i = tid; i < 32 * DKB * WTLD; i += 256) {
+        const int d = i / WTLD, mm = i - d * WTLD;
+        wT[i] = (d < dh && mm < m) ? W[(long)mm * dh + d] : from_f32<T>(0.f);
+    }
+    for (int i = tid; i < 32 * DKB * RLD + MP; i += 256) red[i] = 0.f;
+    __syncthreads();
+
+    const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * L * p.ld + h * dh;
+    const T* OUT = reinterpret_cast<const T*>(p.out) + (long)b * L * p.ldo + h * dh;
+    const T* DO = reinterpret_cast<const T*>(p.dout) + (long)b * L * p.ldo + h * dh;
+    const T* KV = reinterpret_cast<const T*>(p.kv) + ((long)b * p.H + h) * p.mp * p.dhp;
+    const float* KS = p.ksum + ((long)b * p.H + h) * p.mp;
+    const float* KV32 = p.kv32 + ((long)b * p.H + h) * p.mp * p.dhp;
+
+    f32x4 dkvt[ND][MT];
+    float dks[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        dks[mt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) dkvt[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int l0 = 16 * wave; l0 < L; l0 += 64) {
+        const int l = l0 + li;
+        stage_rows<T, DKB>(dOw, DO, p.ldo, l0, 16, 0, L, dh, lane, 64);
+        Frag<T> xf[DKB];
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(xf[kb], Q, p.ld, l, L, dh, kb, lane);
+        // ---- phase A: lane = token -------------------------------------------------------------
+        f32x4 dd[MT];
+        ddT_tiles<T, DKB, MT>(dd, xf, W, m, dh, lane);
+        const float diag = row_sum<T, DKB>(xf) * p.diag_c;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * mt + 4 * g + r < m) mx = fmaxf(mx, dd[mt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float den = 0.f;
+        f32x4 qp[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ksv = *reinterpret_cast<const f32x4*>(KS + 16 * mt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = 16 * mt + 4 * g + r < m;
+                qp[mt][r] = ok ? feat(p.kind, dd[mt][r], diag, mx, p.ratio, p.eps) : 0.f;
+                den += qp[mt][r] * ksv[r];
+            }
+        }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float inv = (l < L) ? 1.f / den : 0.f;
+        // dnum^T tiles (acc layout: rows d = 16dt+4g+r, column = token) and dden
+        f32x4 dnum[ND];
+        float dden = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            f32x4 go = {0.f, 0.f, 0.f, 0.f}, oo = {0.f, 0.f, 0.f, 0.f};
+            if (l < L && d0 < dh) {
+                go = load4<T>(DO + (long)l * p.ldo + d0);
+                oo = load4<T>(OUT + (long)l * p.ldo + d0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dden -= go[r] * oo[r];
+            dnum[dt] = go * inv;
+        }
+        dden += __shfl_xor(dden, 16, 64);
+        dden += __shfl_xor(dden, 32, 64);
+        dden *= inv;
+        // dq'^T[m][l] = sum_d KV[m][d] dnum^T[d][l] + dden ksum[m];  e = dq' * feat'
+        float esum = 0.f;
+        f32x4 e[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            const int mrow = 16 * mt + li;
+#pragma unroll
+            for (int kb = 0; kb < DKB; ++kb) {
+                if constexpr (sizeof(T) == 2) {
+                    const float* kr = KV32 + (long)mrow * p.dhp + 32 * kb + 4 * g;
+                    Frag<__bf16> ah, alo, bh, blo;
+                    acc_to_frag_hilo(ah, alo, *reinterpret_cast<const f32x4*>(kr), *reinterpret_cast<const f32x4*>(kr + 16));
+                    acc_to_frag_hilo(bh, blo, dnum[2 * kb], dnum[2 * kb + 1]);
+                    s = mma(ah, bh, s);
+                    s = mma(ah, blo, s);
+                    s = mma(alo, bh, s);
+                } else {
+                    Frag<T> a, bn;
+                    frag_load_split<T>(a, KV + (long)mrow * p.dhp + 32 * kb + 4 * g, KV + (long)mrow * p.dhp + 32 * kb + 16 + 4 * g, true);
+                    acc_to_frag(bn, dnum[2 * kb], dnum[2 * kb + 1]);
+                    s = mma(a, bn, s);
+                }
+            }
+            const f32x4 ksv = *reinterpret_cast<const f32x4*>(KS + 16 * mt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = 16 * mt + 4 * g + r < m;
+                const float dqp = s[r] + dden * ksv[r];
+                e[mt][r] = ok ? dqp * feat_grad(p.kind, dd[mt][r], diag, mx, p.ratio) : 0.f;
+                esum += e[mt][r];
+            }
+        }
+        esum += __shfl_xor(esum, 16, 64);
+        esum += __shfl_xor(esum, 32, 64);
+        if (p.kind == FAVOR_SOFTMAX) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * mt + 4 * g + r < m && dd[mt][r] == mx) e[mt][r] -= esum;
+        }
+        const float ddiag = p.kind == FAVOR_SOFTMAX ? -esum * p.diag_c : 0.f;
+        // dQ^T[d][l] = sum_m w^T[d][m] ddd^T[m][l] + ddiag
+        T* DQ = reinterpret_cast<T*>(p.dq) + ((long)b * L + l) * p.ld_d + h * dh;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            f32x4 s = {ddiag, ddiag, ddiag, ddiag};
+            const T* wrow = wT + (16 * dt + li) * WTLD;
+#pragma unroll
+            for (int mb = 0; mb < (MT + 1) / 2; ++mb) {
+                const bool has2 = 2 * mb + 1 < MT;
+                Frag<T> a, be;
+                frag_load_split<T>(a, wrow + 32 * mb + 4 * g, wrow + 32 * mb + 16 + 4 * g, has2);
+                acc_to_frag(be, e[2 * mb], has2 ? e[2 * mb + 1] : f32x4{0.f, 0.f, 0.f, 0.f});
+                s = mma(a, be, s);
+            }
+            const int d0 = 16 * dt + 4 * g;
+            if (l < L && d0 < dh) store4<T>(DQ + d0, s);
+        }
+        // hand the per-token scalars to phase B (rows in registers need them by row index)
+        if (g == 0) {
+            rowv[li] = inv;
+            rowv[16 + li] = dden;
+            rowv[32 + li] = mx;
+            rowv[48 + li] = diag;
+        }
+        wave_lds_sync();
+        // ---- phase B: tokens in accumulator rows: dKV^T[d][m] += dO^T[d][l] (q'[l][m] / den[l]) ----
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < DKB; ++kb) {
+                Frag<T> wf;
+                row_frag_global<T>(wf, W, dh, 16 * mt + li, m, dh, kb, lane);
+                s = mma(xf[kb], wf, s);                 // dd[token 4g+r][feature 16mt+li]
+            }
+            f32x4 qn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = 4 * g + r;
+                const bool ok = (l0 + lr < L) && (16 * mt + li < m);
+                const float v = ok ? feat(p.kind, s[r], rowv[48 + lr], rowv[32 + lr], p.ratio, p.eps) : 0.f;
+                dks[mt] += v * rowv[16 + lr];
+                qn[r] = v * rowv[lr];
+            }
+            Frag<T> bq;
+            acc_to_frag(bq, qn, f32x4{0.f, 0.f, 0.f, 0.f});     // 16 tokens: second half of K is zero
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                Frag<T> a;
+                col_frag(a, dOw, ASTR, 4 * g, 4 * g, 16 * dt, lane);
+                dkvt[dt][mt] = mma(a, bq, dkvt[dt][mt]);
+            }
+        }
+        wave_lds_sync();
+    }
+    // reduce over the 4 waves and write dKV in both layouts (+ fp32 transposed copy) and dksum
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float s = dks[mt];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (g == 0) atomicAdd(&dksr[16 * mt + li], s);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li], dkvt[dt][mt][r]);
+    }
+    __syncthreads();
+    T* DKVT = reinterpret_cast<T*>(p.dkvt_t) + ((long)b * p.H + h) * dh * p.mp;
+    T* DKV = reinterpret_cast<T*>(p.dkv_t) + ((long)b * p.H + h) * p.mp * p.dhp;
+    float* DKS = p.dksum + ((long)b * p.H + h) * p.mp;
+    for (int i = tid; i < p.dhp * MP; i += 256) {
+        const int d = i / MP, mm = i - d * MP;
+        const float v = d < dh ? red[d * RLD + mm] : 0.f;
+        if (d < dh) DKVT[(long)d * p.mp + mm] = from_f32<T>(v);
+        DKV[(long)mm * p.dhp + d] = from_f32<T>(v);
+        p.dkv32[(((long)b * p.H + h) * p.mp + mm) * p.dhp + d] = v;
+    }
+    for (int i = tid; i < MP; i += 256) DKS[i] = dksr[i];
+}
+
+// ------------------------------------------------------------------ backward, key / value side
+// grid (ceil(L / 64), H, B); lane = token.
+//   dk'[l][m] = dKV[m] . v[l] + dksum[m];  e = dk' * feat';  esum(global) += sum e
+//   dK[l] = e[l] . w - (sum_m e[l][m]) diag_c      (the global-max term is applied by favor_fix)
+//   dV[l] = k'[l] . dKV
+template <typename T, int DKB, int MT>
+__global__ __launch_bounds__(256) void favor_bwd_kv_kernel(const FavorParams p) {
+    constexpr int ND = 2 * DKB;
+    constexpr int MP = 16 * MT;
+    constexpr int WTLD = MP + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int l0 = blockIdx.x * 64 + 16 * wave, h = blockIdx.y, b = blockIdx.z;
+    const int L = p.L, dh = p.dh, m = p.m;
+    T* wT = reinterpret_cast<T*>(smem);
+    const T* W = reinterpret_cast<const T*>(p.w);
+    for (int i = tid; i < 32 * DKB * WTLD; i += 256) {
+        const int d = i / WTLD, mm = i - d * WTLD;
+        wT[i] = (d < dh && mm < m) ? W[(long)mm * dh + d] : from_f32<T>(0.f);
+    }
+    __syncthreads();
+    if (l0 >= L) return;
+    const int l = l0 + li;
+    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
+    const T* V = reinterpret_cast<const T*>(p.v) + (long)b * L * p.ld + h * dh;
+    const T* DKV = reinterpret_cast<const T*>(p.dkv_t) + ((long)b * p.H + h) * p.mp * p.dhp;
+    const T* DKVT = reinterpret_cast<const T*>(p.dkvt_t) + ((long)b * p.H + h) * dh * p.mp;
+    const float* DKS = p.dksum + ((long)b * p.H + h) * p.mp;
+    const float* DKV32 = p.dkv32 + ((long)b * p.H + h) * p.mp * p.dhp;
+    float stab = 0.f;
+    if (p.kind == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(*p.kmax >> 32));
+
+    Frag<T> xf[DKB], vf[DKB];
+#pragma unroll
+    for (int kb = 0; kb < DKB; ++kb) {
+        row_frag_global<T>(xf[kb], K, p.ld, l, L, dh, kb, lane);
+        row_frag_global<T>(vf[kb], V, p.ld, l, L, dh, kb, lane);
+    }
+    f32x4 dd[MT];
+    ddT_tiles<T, DKB, MT>(dd, xf, W, m, dh, lane);
+    const float diag = row_sum<T, DKB>(xf) * p.diag_c;
+    f32x4 kp[MT], e[MT];
+    float esum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < DKB; ++kb) {
+            if constexpr (sizeof(T) == 2) {
+                const float* dr = DKV32 + (long)(16 * mt + li) * p.dhp + 32 * kb + 8 * g;
+                Frag<__bf16> ah, alo;
+                acc_to_frag_hilo(ah, alo, *reinterpret_cast<const f32x4*>(dr), *reinterpret_cast<const f32x4*>(dr + 4));
+                s = mma(ah, vf[kb], s);
+                s = mma(alo, vf[kb], s);
+            } else {
+                Frag<T> a;
+                row_frag_global<T>(a, DKV, p.dhp, 16 * mt + li, p.mp, p.dhp, kb, lane);   // rows m of dKV
+                s = mma(a, vf[kb], s);                                                    // dk'^T[m][l]
+            }
+        }
+        const f32x4 dksv = *reinterpret_cast<const f32x4*>(DKS + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = (16 * mt + 4 * g + r < m) && (l < L);
+            kp[mt][r] = ok ? feat(p.kind, dd[mt][r], diag, stab, p.ratio, p.eps) : 0.f;
+            e[mt][r] = ok ? (s[r] + dksv[r]) * feat_grad(p.kind, dd[mt][r], diag, stab, p.ratio) : 0.f;
+            esum += e[mt][r];
+        }
+    }
+    float esum_l = esum;
+    esum_l += __shfl_xor(esum_l, 16, 64);
+    esum_l += __shfl_xor(esum_l, 32, 64);
+    if (p.kind == FAVOR_SOFTMAX) {
+        float tot = wave_sum(esum);
+        if (lane == 0) atomicAdd(p.esum, tot);
+    }
+    const float ddiag = p.kind == FAVOR_SOFTMAX ? -esum_l * p.diag_c : 0.f;
+    T* DK = reinterpret_cast<T*>(p.dk) + ((long)b * L + l) * p.ld_d + h * dh;
+    T* DV = reinterpret_cast<T*>(p.dv) + ((long)b * L + l) * p.ld_d + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        f32x4 sk = {ddiag, ddiag, ddiag, ddiag}, sv = {0.f, 0.f, 0.f, 0.f};
+        const T* wrow = wT + (16 * dt + li) * WTLD;
+        const int d = 16 * dt + li;
+#pragma unroll
+        for (int mb = 0; mb < (MT + 1) / 2; ++mb) {
+            const bool has2 = 2 * mb + 1 < MT;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            Frag<T> a, be, a2, bk;
+            frag_load_split<T>(a, wrow + 32 * mb + 4 * g, wrow + 32 * mb + 16 + 4 * g, has2);
+            acc_to_frag(be, e[2 * mb], has2 ? e[2 * mb + 1] : zero);
+            sk = mma(a, be, sk);
+            if (d < dh) frag_load_split<T>(a2, DKVT + (long)d * p.mp + 32 * mb + 4 * g, DKVT + (long)d * p.mp + 32 * mb + 16 + 4 * g, has2);
+            else frag_zero(a2);
+            acc_to_frag(bk, kp[2 * mb], has2 ? kp[2 * mb + 1] : zero);
+            sv = mma(a2, bk, sv);
+        }
+        const int d0 = 16 * dt + 4 * g;
+        if (l < L && d0 < dh) {
+            store4<T>(DK + d0, sk);
+            store4<T>(DV + d0, sv);
+        }
+    }
+}
+
+// the global-max element of the key features receives minus the whole tensor's exp-gradient sum
+template <typename T>
+__global__ void favor_fix_kernel(const FavorParams p) {
+    const unsigned long long key = *p.kmax;
+    const unsigned long long idx = 0xffffffffull - (key & 0xffffffffull);
+    const int mi = idx % p.m;
+    const unsigned long long t = idx / p.m;
+    const int h = t % p.H;
+    const long bl = t / p.H;
+    const float s = *p.esum;
+    const T* W = reinterpret_cast<const T*>(p.w);
+    T* DK = reinterpret_cast<T*>(p.dk) + bl * p.ld_d + h * p.dh;
+    for (int d = threadIdx.x; d < p.dh; d += blockDim.x)
+        DK[d] = from_f32<T>(to_f32<T>(DK[d]) - s * to_f32<T>(W[(long)mi * p.dh + d]));
+}
+
+}  // namespace vitk
+
+using namespace vitk;
+
+namespace {
+
+bool f16al(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+int pick_mt(int m) { return m <= 16 ? 1 : (m <= 64 ? 4 : 16); }
+
+template <typename T, int DKB, int MT> void launch_fwd(const FavorParams& p, hipStream_t st) {
+    using C = ACfg<T, DKB>;
+    constexpr int MTC = MT >= 4 ? 4 : 1;
+    if (p.kind == FAVOR_SOFTMAX) {
+        (void)hipMemsetAsync(p.kmax, 0, 8, st);
+        hipLaunchKernelGGL((favor_kmax_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), 0, st, p);
+    }
+    const size_t lds = (size_t)4 * 32 * C::ASTR * sizeof(T) + (size_t)(32 * DKB * (16 * MTC + 4) + 16 * MTC) * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)favor_kv_kernel<T, DKB, MTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((favor_kv_kernel<T, DKB, MTC>), dim3(MT / MTC, p.H, p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((favor_out_kernel<T, DKB, MT>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), 0, st, p);
+}
+
+template <typename T, int DKB, int MT> void launch_bwd(const FavorParams& p, hipStream_t st) {
+    using C = ACfg<T, DKB>;
+    constexpr int MP = 16 * MT;
+    if (p.kind == FAVOR_SOFTMAX) (void)hipMemsetAsync(p.esum, 0, 4, st);
+    const size_t lds_q = (size_t)(32 * DKB * (MP + 8) + 4 * 16 * C::ASTR) * sizeof(T) +
+                         (size_t)(32 * DKB * (MP + 4) + MP + 4 * 64) * 4;
+    const size_t lds_k = (size_t)(32 * DKB * (MP + 8)) * sizeof(T);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)favor_bwd_q_kernel<T, DKB, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        (void)hipFuncSetAttribute((const void*)favor_bwd_kv_kernel<T, DKB, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+        attr = true;
+    }
+    hipLaunchKernelGGL((favor_bwd_q_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), lds_q, st, p);
+    hipLaunchKernelGGL((favor_bwd_kv_kernel<T, DKB, MT>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), lds_k, st, p);
+    if (p.kind == FAVOR_SOFTMAX) hipLaunchKernelGGL(favor_fix_kernel<T>, dim3(1), dim3(64), 0, st, p);
+}
+
+template <typename T, int DKB> void dispatch_mt(const FavorParams& p, bool bwd, hipStream_t st) {
+    const int mt = pick_mt(p.m);
+#define VITK_FV(M)                                  \
+    do {                                            \
+        if (bwd) launch_bwd<T, DKB, M>(p, st);      \
+        else launch_fwd<T, DKB, M>(p, st);          \
+    } while (0)
+    if (mt == 1) VITK_FV(1);
+    else if (mt == 4) VITK_FV(4);
+    else VITK_FV(16);
+#undef VITK_FV
+}
+
+void dispatch(const FavorParams& p, int dtype, bool bwd, hipStream_t st) {
+    const int dkb = (p.dh + 31) / 32;
+    if (dtype == VITK_BF16) {
+        if (dkb == 1) dispatch_mt<__bf16, 1>(p, bwd, st);
+        else dispatch_mt<__bf16, 2>(p, bwd, st);
+    } else {
+        if (dkb == 1) dispatch_mt<float, 1>(p, bwd, st);
+        else dispatch_mt<float, 2>(p, bwd, st);
+    }
+}
+
+}  // namespace
+
+// Workspace layout (bytes, all 256-byte aligned), esz = element size of T, mp = 16 * MT, dhp = 32 * DKB:
+//   kmax (8) | esum (4) | ksum fp32 [B*H*mp] | dksum fp32 [B*H*mp] | KVT T [B*H*dh*mp] | KV T [B*H*mp*dhp]
+//   | dKVT T | dKV T | KV fp32 [B*H*mp*dhp] | dKV fp32
+// The forward fills kmax, ksum, KVT, KV; the backward reads them, so the SAME workspace must be
+// passed to both calls of one step (it is the saved state of the op).
+extern "C" long vitk_favor_workspace_bytes(int dtype, int B, int H, int dh, int m) {
+    const long esz = dtype == VITK_BF16 ? 2 : 4;
+    const long mp = 16 * pick_mt(m), dhp = 32 * ((dh + 31) / 32);
+    const long bh = (long)B * H;
+    auto al = [](long x) { return (x + 255) / 256 * 256; };
+    return 256 + 2 * al(bh * mp * 4) + 2 * al(bh * dh * mp * esz) + 2 * al(bh * mp * dhp * esz) + 2 * al(bh * mp * dhp * 4);
+}
+
+static int favor_setup(FavorParams& p, int dtype, int kind, int B, int H, int L, int dh, int m, float ratio, float eps,
+                       void* workspace) {
+    const long esz = dtype == VITK_BF16 ? 2 : 4;
+    const long mp = 16 * pick_mt(m), dhp = 32 * ((dh + 31) / 32);
+    const long bh = (long)B * H;
+    auto al = [](long x) { return (x + 255) / 256 * 256; };
+    char* ws = reinterpret_cast<char*>(workspace);
+    p.kmax = reinterpret_cast<unsigned long long*>(ws);
+    p.esum = reinterpret_cast<float*>(ws + 8);
+    ws += 256;
+    p.ksum = reinterpret_cast<float*>(ws); ws += al(bh * mp * 4);
+    p.dksum = reinterpret_cast<float*>(ws); ws += al(bh * mp * 4);
+    p.kvt = ws; ws += al(bh * dh * mp * esz);
+    p.kv = ws; ws += al(bh * mp * dhp * esz);
+    p.dkvt_t = ws; ws += al(bh * dh * mp * esz);
+    p.dkv_t = ws; ws += al(bh * mp * dhp * esz);
+    p.kv32 = reinterpret_cast<float*>(ws); ws += al(bh * mp * dhp * 4);
+    p.dkv32 = reinterpret_cast<float*>(ws);
+    p.dkvt = nullptr;
+    p.B = B; p.H = H; p.L = L; p.dh = dh; p.m = m; p.mp = (int)mp; p.dhp = (int)dhp;
+    p.kind = kind; p.ratio = ratio; p.eps = eps;
+    p.diag_c = 0.5f / sqrtf((float)dh);
+    return 0;
+}
+
+#define FAVOR_COMMON_CHECKS(name)                                                                                  \
+    VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, name ": bad dtype");                                   \
+    VITK_CHECK_ARG(kind == FAVOR_SOFTMAX || kind == FAVOR_RELU, name ": kernel must be 0 (softmax) or 1 (relu)");  \
+    VITK_CHECK_ARG(B > 0 && H > 0 && L > 0, name ": empty problem");                                               \
+    VITK_CHECK_ARG(dh > 0 && dh <= 64 && (dh * (dtype == VITK_BF16 ? 2 : 4)) % 16 == 0, name ": head dim %d unsupported", dh); \
+    VITK_CHECK_ARG(m > 0 && m <= 256, name ": 1..256 random features supported, got %d", m);                       \
+    VITK_CHECK_ARG((long)B * L * H * m < 0xffffffffL, name ": feature tensor too large for the argmax index");     \
+    VITK_CHECK_ARG(workspace && f16al(workspace), name ": workspace must be 16-byte aligned");                     \
+    VITK_CHECK_ARG(H <= 65535 && B <= 65535, name ": grid too large")
+
+// out = FAVOR+ attention(q, k, v; w).  kind 0 = softmax kernel, 1 = relu kernel; ratio / eps as the
+// reference computes them (m^-1/4 or m^-1/2; 1e-6 or 1e-3).  w: [m][dh] in T, contiguous.
+extern "C" int vitk_favor_fwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                              const void* v, long ld, const void* w, float ratio, float eps, void* out, long ldo,
+                              void* workspace, hipStream_t stream) {
+    FAVOR_COMMON_CHECKS("vitk_favor_fwd");
+    const long esz = dtype == VITK_BF16 ? 2 : 4;
+    VITK_CHECK_ARG(q && k && v && w && out, "vitk_favor_fwd: null pointer");
+    VITK_CHECK_ARG(f16al(q) && f16al(k) && f16al(v) && f16al(out) && f16al(w) && (ld * esz) % 16 == 0 &&
+                       (ldo * esz) % 16 == 0 && ld >= (long)H * dh && ldo >= (long)H * dh,
+                   "vitk_favor_fwd: rows must be 16-byte aligned and at least H*dh wide");
+    FavorParams p = {};
+    favor_setup(p, dtype, kind, B, H, L, dh, m, ratio, eps, workspace);
+    p.q = q; p.k = k; p.v = v; p.ld = ld; p.w = w; p.out = out; p.ldo = ldo;
+    dispatch(p, dtype, false, stream);
+    VITK_CHECK_LAUNCH("vitk_favor_fwd");
+    return VITK_OK;
+}
+
+extern "C" int vitk_favor_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                              const void* v, long ld, const void* w, float ratio, float eps, const void* out,
+                              const void* dout, long ldo, void* dq, void* dk, void* dv, long ld_d, void* workspace,
+                              hipStream_t stream) {
+    FAVOR_COMMON_CHECKS("vitk_favor_bwd");
+    const long esz = dtype == VITK_BF16 ? 2 : 4;
+    VITK_CHECK_ARG(q && k && v && w && out && dout && dq && dk && dv, "vitk_favor_bwd: null pointer");
+    VITK_CHECK_ARG(f16al(q) && f16al(k) && f16al(v) && f16al(out) && f16al(dout) && f16al(w) && f16al(dq) && f16al(dk) &&
+                       f16al(dv) && (ld * esz) % 16 == 0 && (ldo * esz) % 16 == 0 && (ld_d * esz) % 16 == 0 &&
+                       ld >= (long)H * dh && ldo >= (long)H * dh && ld_d >= (long)H * dh,
+                   "vitk_favor_bwd: rows must be 16-byte aligned and at least H*dh wide");
+    FavorParams p = {};
+    favor_setup(p, dtype, kind, B, H, L, dh, m, ratio, eps, workspace);
+    p.q = q; p.k = k; p.v = v; p.ld = ld; p.w = w;
+    p.out = const_cast<void*>(out); p.dout = dout; p.ldo = ldo;
+    p.dq = dq; p.dk = dk; p.dv = dv; p.ld_d = ld_d;
+    dispatch(p, dtype, true, stream);
+    VITK_CHECK_LAUNCH("vitk_favor_bwd");
+    return VITK_OK;
+}

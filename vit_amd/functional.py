@@ -418,3 +418,41 @@ class MlpFn(torch.autograd.Function):
 
 def mlp(x2d, w1, b1, w2, b2, act='gelu'):
     return MlpFn.apply(x2d, w1, b1, w2, b2, act)
+
+
+# --------------------------------------------------------------------------- FAVOR+ (Performer)
+class FavorAttentionFn(torch.autograd.Function):
+    """FAVOR+ linear attention on a packed qkv buffer: feature maps (softmax / relu kernel, with
+    the reference's stabilisers) + KV contraction + normaliser, forward and backward in HIP."""
+
+    @staticmethod
+    def forward(ctx, qkv, w, B, L, H, dh, kind, ratio, eps):
+        D = H * dh
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        ws = ops.favor_workspace(qkv, B, H, dh, w.shape[0])
+        out = ops.favor_fwd(q, k, v, B, H, L, dh, qkv.stride(0), w, kind, ratio, eps, ws)
+        ctx.save_for_backward(qkv, w, out, ws)
+        ctx.cfg = (B, L, H, dh, kind, ratio, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, w, out, ws = ctx.saved_tensors
+        B, L, H, dh, kind, ratio, eps = ctx.cfg
+        D = H * dh
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        dqkv = torch.empty_like(qkv)
+        ops.favor_bwd(q, k, v, B, H, L, dh, qkv.stride(0), w, kind, ratio, eps, out, dout.contiguous(),
+                      dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, ws)
+        return dqkv, None, None, None, None, None, None, None, None
+
+
+def favor_attention(qkv, w, B, L, H, dh, kernel, ratio):
+    """kernel: 'softmax' (eps 1e-6) or 'relu' (eps 1e-3), as the reference's two feature maps."""
+    if kernel == 'softmax':
+        kind, eps = ops.FAVOR_SOFTMAX, 1e-6
+    elif kernel == 'relu':
+        kind, eps = ops.FAVOR_RELU, 1e-3
+    else:
+        raise ValueError(f'unknown FAVOR+ kernel {kernel!r}')
+    return FavorAttentionFn.apply(qkv, w.to(qkv.dtype).contiguous(), B, L, H, dh, kind, float(ratio), eps)

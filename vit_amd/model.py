@@ -7,6 +7,7 @@ Token matrices travel as 2-D ``[B*N, D]`` tensors in the compute dtype between f
 the reference's ``[N, B, D]`` layout appears only at the module boundaries that expose it.
 """
 import copy
+import math
 from functools import partial
 
 import torch
@@ -15,6 +16,7 @@ import torch.nn as nn
 from . import functional as VF
 from .precision import ComputeDtypeMixin
 from .timm_classes.timm_locality_aware_transformer import PatchEmbed, _check_p0  # noqa: F401
+from .timm_classes.timm_vision_performer import gaussian_orthogonal_random_matrix, orthogonal_matrix_chunk
 
 
 class VisionTransformer(ComputeDtypeMixin, nn.Module):
@@ -184,6 +186,56 @@ class Transformer(ComputeDtypeMixin, nn.Module):
     def forward(self, src, pos_embed):
         """[B, N, D] -> [N, B, D]; pos_embed is accepted and never added (model.py:185,198)."""
         return self.encoder(src.permute(1, 0, 2), pos=None)
+
+
+class MultiheadAttentionPerformer(ComputeDtypeMixin, nn.MultiheadAttention):
+    """FAVOR+ attention on ``nn.MultiheadAttention`` parameters (model.py:248-388): [L, B, E] in,
+    (out [L, B, E], None) out.  Differences from PerformerAttention kept as upstream: the softmax
+    feature map scales by m^-1/2 (:323), the relu one by m^-1/4 (:347)."""
+
+    def __init__(self, d_model, nhead, dropout=0.1, num_orf=32, kernel='softmax'):
+        super().__init__(d_model, nhead, dropout=dropout)
+        self.kernel = kernel
+        self.m = int(num_orf)
+        self.w = None
+
+    gaussian_orthogonal_random_matrix = staticmethod(gaussian_orthogonal_random_matrix)
+    orthogonal_matrix_chunk = staticmethod(orthogonal_matrix_chunk)
+
+    def ratio(self):
+        return 1.0 / math.sqrt(self.m) if self.kernel == 'softmax' else 1.0 / math.sqrt(math.sqrt(self.m))
+
+    def forward2d(self, x2, B, N):
+        """[B*N, E] batch-major rows in compute dtype -> [B*N, E]."""
+        _check_p0(self, self.dropout)
+        if not self._qkv_same_embed_dim:
+            raise NotImplementedError('separate q/k/v embedding dims are not used by the reference models')
+        if self.w is None:
+            self.w = gaussian_orthogonal_random_matrix(self.m, self.head_dim, device=x2.device)
+        qkv = VF.linear(x2, self.in_proj_weight, self.in_proj_bias)
+        y = VF.favor_attention(qkv, self.w.to(x2.device), B, N, self.num_heads, self.head_dim, self.kernel, self.ratio())
+        return VF.linear(y, self.out_proj.weight, self.out_proj.bias)
+
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None):
+        if not (query is key and key is value):
+            raise NotImplementedError('MultiheadAttentionPerformer: self-attention (q = k = v) only on the hot path')
+        L, B, E = query.shape
+        x2 = query.permute(1, 0, 2).reshape(B * L, E).to(self.compute_dtype)
+        y = self.forward2d(x2, B, L)
+        return y.view(B, L, E).permute(1, 0, 2).to(query.dtype), None
+
+
+class Performer(Transformer):
+    """model.py:391-408: the stock encoder with every self_attn replaced by FAVOR+."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, dropout=0.1,
+                 activation="relu", normalize_before=False, return_intermediate_dec=False, num_orf=64, kernel='relu'):
+        super().__init__(d_model=d_model, nhead=nhead, num_encoder_layers=num_encoder_layers,
+                         dim_feedforward=dim_feedforward, dropout=dropout, activation=activation,
+                         normalize_before=normalize_before, return_intermediate_dec=return_intermediate_dec)
+        for layer in self.encoder.layers:
+            layer.self_attn = MultiheadAttentionPerformer(d_model, nhead, dropout=dropout, num_orf=num_orf,
+                                                          kernel=kernel)
 
 
 def build_transformer(args):

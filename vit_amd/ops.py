@@ -232,3 +232,36 @@ def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, l
                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d,
                              _ptr(dpk), _ptr(dpq), H * dh if ld_dp is None else ld_dp, workspace.data_ptr(), _stream())
     check(st, 'vitk_attn_bwd')
+
+
+FAVOR_SOFTMAX, FAVOR_RELU = 0, 1
+
+
+def favor_workspace(q, B, H, dh, m):
+    n = lib().vitk_favor_workspace_bytes(_dt(q), B, H, dh, m)
+    return torch.empty(n, device=q.device, dtype=torch.uint8)
+
+
+def favor_fwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, workspace):
+    """FAVOR+ attention forward on views of a packed qkv buffer (element (b,l,h,d) at (b*L+l)*ld + h*dh + d).
+    w: [m, dh] in the compute dtype.  ``workspace`` (favor_workspace) receives KV / ksum / the key
+    max and must be handed unchanged to favor_bwd.  Returns out [B*L, H*dh]."""
+    _req_cuda(q, k, v, w, workspace)
+    if w.dtype != q.dtype or not w.is_contiguous() or w.shape[1] != dh:
+        raise ValueError('favor: w must be contiguous [m, dh] in the compute dtype')
+    out = torch.empty(B * L, H * dh, device=q.device, dtype=q.dtype)
+    st = lib().vitk_favor_fwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(), ld,
+                              w.data_ptr(), float(ratio), float(eps), out.data_ptr(), H * dh,
+                              workspace.data_ptr(), _stream())
+    check(st, 'vitk_favor_fwd')
+    return out
+
+
+def favor_bwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, out, dout, dq, dk, dv, ld_d, workspace):
+    _req_cuda(q, k, v, w, out, dout, dq, dk, dv, workspace)
+    if not (out.is_contiguous() and dout.is_contiguous()) or dout.shape != out.shape:
+        raise ValueError('favor_bwd: out / dout must be contiguous [B*L, H*dh]')
+    st = lib().vitk_favor_bwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(), ld,
+                              w.data_ptr(), float(ratio), float(eps), out.data_ptr(), dout.data_ptr(), H * dh,
+                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d, workspace.data_ptr(), _stream())
+    check(st, 'vitk_favor_bwd')

@@ -119,6 +119,11 @@ class BlockLAI(ComputeDtypeMixin, nn.Module):
         """x2: [B*N, C] in compute dtype -> same.  The whole block is one autograd node."""
         a = self.attn
         _check_p0(self, a.attn_drop.p, a.proj_drop.p, self.mlp.drop.p, self.drop_path_rate)
+        if not isinstance(a, AttentionLAI):      # an attention swapped in (FAVOR+, train.py:147-165)
+            x2 = x2 + a.forward2d(VF.layer_norm(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, N)
+            h = VF.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return x2 + VF.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
+                               'gelu')
         if self.norm1.eps != self.norm2.eps:
             raise NotImplementedError('BlockLAI: norm1 / norm2 must share eps')
         cfg = (B, N, a.num_heads, self.norm1.eps, float(a.scale), lai_stage_width(epoch, a.mask_epochs), 'gelu')

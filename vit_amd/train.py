@@ -11,6 +11,7 @@ from . import model as M
 from .disentangled_transformer.disentangled_transformer import DisentangledTransformer
 from .precision import set_compute_dtype
 from .timm_classes.timm_locality_aware_transformer import VisionTransformerLAI
+from .timm_classes.timm_vision_performer import PerformerAttention
 
 # Presets as the reference names them (README.md:50-54): S/16 = 12 L x 768 (== timm
 # vit_base_patch16_224, train.py:121), B/16 = 24 L x 1024 x 16 h, L/16 = 32 L x 1280 x 16 h.
@@ -34,7 +35,7 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
     """Model factory for the --attention variants on the hot path (train.py:97-253):
     'transformer' (regular, pre-LN, ReLU), 'transformer_timm_lai', 'disentangled_attention',
     'disentangled_lai_attention'.  Dropout is 0 (parity and benchmarks are defined at p = 0)."""
-    p = dict(PRESETS[preset], **over)
+    p = dict(PRESETS[preset], **{k: v for k, v in over.items() if k in ('depth', 'dim', 'mlp', 'heads')})
     if attention == 'transformer':
         tr = M.Transformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
                            num_encoder_layers=p['depth'], normalize_before=True)
@@ -51,6 +52,21 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
                                      num_encoder_layers=p['depth'], normalize_before=True, pos_att_type='c2p|p2c',
                                      max_position_embeddings=p['dim'], relative_attention=True, lai=lai,
                                      mask_epochs=mask_epochs if lai else None)
+        net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                  num_classes=num_classes, transformer=tr)
+    elif attention == 'performer_timm':
+        # train.py:147-165: a timm ViT whose every blk.attn is replaced by PerformerAttention
+        net = VisionTransformerLAI(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                   num_classes=num_classes, embed_dim=p['dim'], depth=p['depth'],
+                                   num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'], qkv_bias=True,
+                                   mask_epochs=None)
+        for blk in net.blocks:
+            blk.attn = PerformerAttention(blk.attn, p['dim'], num_heads=p['heads'], qkv_bias=True,
+                                          n_orf=over.get('num_orf', 64), kernel=over.get('kernel', 'softmax'))
+    elif attention == 'performer':
+        tr = M.Performer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+                         num_encoder_layers=p['depth'], normalize_before=True,
+                         num_orf=over.get('num_orf', 64), kernel=over.get('kernel', 'softmax'))
         net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
                                   num_classes=num_classes, transformer=tr)
     else:
