@@ -299,6 +299,10 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
         }
     }
     splitk = splitk < 1 ? 1 : (splitk > ksteps ? (ksteps > 0 ? ksteps : 1) : splitk);
+    if (splitk > 1) {   // no empty K split: the kernels assume every split owns at least one K step
+        const int per = (ksteps + splitk - 1) / splitk;
+        splitk = (ksteps + per - 1) / per;
+    }
     if (splitk > 1) {
         VITK_CHECK_ARG(c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out,
                        "vitk_gemm: split-K needs an fp32 output and a linear epilogue");
@@ -318,6 +322,7 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
     }
     p.splitk = splitk;
     p.tiles_m = tiles_m; p.tiles_n = tiles_n;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VITK_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
     if (big) {
         gemm256_launch(p, c_dtype, transA, transB, stream);
         VITK_CHECK_LAUNCH("vitk_gemm");

@@ -30,6 +30,7 @@ struct GemmParams {
     int c_vec8_ok;           // 8-column (16-byte) epilogue accesses legal
     float alpha;
     int tiles_m, tiles_n;
+    int debug;
 };
 
 
@@ -157,6 +158,11 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int split, i
 
 // Same for 8 consecutive columns (16-byte bf16 accesses): used by the 256-tile kernel, whose
 // epilogue re-reads the accumulators row-major from LDS so that 8 lanes cover a 128-byte line.
+// gemm_epilogue8_fast: the caller has checked c_vec8_ok, n8 + 7 < N, splitk == 1, bf16 operands.
+template <typename T, typename TC>
+__device__ __forceinline__ void gemm_epilogue8_fast(const GemmParams& p, int m, int n8, const float (&acc)[8],
+                                                    const float (&bias8)[8]);
+
 template <typename T, typename TC>
 __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int split, int m, int n8, const float (&acc)[8],
                                                const float (&bias8)[8]) {
@@ -167,6 +173,13 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int split, i
         gemm_epilogue4<T, TC>(p, split, m, n8 + 4, f32x4{acc[4], acc[5], acc[6], acc[7]});
         return;
     }
+    gemm_epilogue8_fast<T, TC>(p, m, n8, acc, bias8);
+}
+
+template <typename T, typename TC>
+__device__ __forceinline__ void gemm_epilogue8_fast(const GemmParams& p, int m, int n8, const float (&acc)[8],
+                                                    const float (&bias8)[8]) {
+    if (m >= p.M) return;
     TC* __restrict__ C = reinterpret_cast<TC*>(p.C);
     const __bf16* __restrict__ aux_in = reinterpret_cast<const __bf16*>(p.aux_in);
     __bf16* __restrict__ aux_out = reinterpret_cast<__bf16*>(p.aux_out);
