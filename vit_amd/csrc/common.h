@@ -107,6 +107,32 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// erf-GELU for the bf16 epilogues (~16 VALU per element instead of ~35-50 of erff / expf: the
+// fused fc1 / dfc2 epilogues are VALU-bound).  erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7,
+// three orders below bf16 rounding); exp(-x^2/2) is shared by erf(x / sqrt 2) and the density.
+// The fp32 parity path keeps erff / expf (gelu_erf, gelu_erf_grad above).
+__device__ __forceinline__ void gelu_fast_parts(float x, float& erfv, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-x^2 / 2)
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    erfv = copysignf(fmaf(-pl * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float erfv, e;
+    gelu_fast_parts(x, erfv, e);
+    const float hx = 0.5f * x;
+    return fmaf(hx, erfv, hx);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float erfv, e;
+    gelu_fast_parts(x, erfv, e);
+    return fmaf(0.5f, erfv, 0.5f) + x * (0.39894228040143267794f * e);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -170,13 +170,13 @@ __device__ __forceinline__ void epi8_regs(const GemmParams& p, long row, int n8,
             *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.aux_out) + row * p.ld_aux + n8) = o;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
     } else if (p.act == ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     } else if (SIDE && p.act == ACT_DGELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)side[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)side[e]);
     } else if (SIDE && p.act == ACT_DRELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)side[e] > 0.f ? v[e] : 0.f;
