@@ -40,10 +40,12 @@ def _worker(rank, world, port, q):
         x, y = xs[rank * 6:(rank + 1) * 6], ys[rank * 6:(rank + 1) * 6]
         ((net(x) - y) ** 2).mean().backward()
         red.finish()
-        out[step] = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+        out[step] = {n: (None if p.grad is None else p.grad.clone().numpy()) for n, p in net.named_parameters()}
     views = all(p.grad is None or p.grad.untyped_storage().data_ptr() in
                 {b.untyped_storage().data_ptr() for b in red.buckets} for p in net.parameters())
-    q.put((rank, {n: p.detach().clone() for n, p in net.named_parameters()}, out, views, len(red.buckets)))
+    # numpy arrays travel as plain pickles (tensors would be passed as file descriptors, which die
+    # with a worker that exits before the parent has received them)
+    q.put((rank, {n: p.detach().clone().numpy() for n, p in net.named_parameters()}, out, views, len(red.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,6 +63,9 @@ def test_reducer_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, w0, g0, v0, nb0), (_, w1, g1, v1, nb1) = res
+    tt = lambda d: {k: (None if v is None else torch.from_numpy(v)) for k, v in d.items()}
+    w0, w1 = tt(w0), tt(w1)
+    g0, g1 = {s: tt(v) for s, v in g0.items()}, {s: tt(v) for s, v in g1.items()}
     assert v0 and v1 and nb0 == nb1 and nb0 > 1
     for n in w0:
         assert torch.equal(w0[n], w1[n]), f'{n}: ranks hold different weights after broadcast'

@@ -58,6 +58,24 @@ def _act_codes(act):
     raise ValueError(f'unsupported activation {act!r}')
 
 
+class _ZeroPool:
+    """One zero-filled fp32 buffer per fused backward, handed out in 64-byte aligned slices: the
+    ten-odd small accumulators of a block (LayerNorm / bias gradients, relative-table gradient)
+    cost one fill kernel instead of one each."""
+
+    def __init__(self, device, *sizes):
+        self.buf = torch.zeros(sum((n + 15) // 16 * 16 for n in sizes), device=device, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        v = self.buf[self.off:self.off + n].view(*shape)
+        self.off += (n + 15) // 16 * 16
+        return v
+
+
 def _dw(dy, x):
     """dW[out, in] = dy^T x in fp32 (split-K over the token dimension)."""
     return ops.gemm(dy, x, trans_a=True, trans_b=False, out_dtype=torch.float32)
@@ -131,19 +149,23 @@ def _attn_fwd(qkv, B, N, H, dh, tables, scale, w):
     return ops.attn_fwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w)
 
 
-def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse):
-    """Returns dqkv [B*N, 3D] and (for tables) fp32 dtables [2N-1, 2D] (dPq | dPk)."""
+def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None):
+    """Returns dqkv [B*N, 3D] and (for tables) fp32 dtables [2N-1, 2D] (dPq | dPk); ``dtab``: a
+    zeroed buffer to accumulate into."""
     D = H * dh
     ld = qkv.stride(0)
     q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
     dqkv = torch.empty(B * N, 3 * D, device=qkv.device, dtype=qkv.dtype)
     dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
-    pq = pk = dpq = dpk = dtab = None
+    pq = pk = dpq = dpk = None
     ld_p = 0
-    if tables is not None:
+    if tables is None:
+        dtab = None
+    else:
         pq, pk = tables[:, :D], tables[:, D:]
         ld_p = tables.stride(0)
-        dtab = torch.zeros(2 * N - 1, 2 * D, device=qkv.device, dtype=torch.float32)
+        if dtab is None:
+            dtab = torch.zeros(2 * N - 1, 2 * D, device=qkv.device, dtype=torch.float32)
         dpq, dpk = dtab[:, :D], dtab[:, D:]
     ops.attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w, out, dout, lse,
                  dq, dk, dv, 3 * D, dpk, dpq, ld_dp=2 * D)
@@ -184,13 +206,13 @@ def _mlp_fwd(x, w1, b1, w2, b2, act, residual):
     return y, hmid, pre
 
 
-def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad):
-    """Returns dx (+ residual_grad), dW1, db1, dW2, db2."""
+def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad, db1=None, db2=None):
+    """Returns dx (+ residual_grad), dW1, db1, dW2, db2 (db1 / db2: zeroed accumulators, optional)."""
     _, bwd_code = _act_codes(act)
-    db2 = ops.colsum(dy)
+    db2 = ops.colsum(dy, out=db2)
     dw2 = _dw(dy, hmid)
     dpre = _dx(dy, w2, act=bwd_code, aux_in=pre if act == 'gelu' else hmid)
-    db1 = ops.colsum(dpre)
+    db1 = ops.colsum(dpre, out=db1)
     dw1 = _dw(dpre, x)
     dx = _dx(dpre, w1, residual=residual_grad)
     return dx, dw1, db1, dw2, db2
@@ -228,18 +250,20 @@ class PreLNBlockFn(torch.autograd.Function):
         dh = D // H
         dt = x.dtype
         dy = dy.contiguous()
-        f32 = dict(device=x.device, dtype=torch.float32)
-        dh2, dw1, db1, dw2, db2 = _mlp_bwd(dy, h2, shadow(w1, dt), shadow(w2, dt), act, hmid, pre, None)
-        dg2, dbe2 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        F = w1.shape[0]
+        zp = _ZeroPool(x.device, D, D, D, D, D, F, D, 3 * D)
+        dh2, dw1, db1, dw2, db2 = _mlp_bwd(dy, h2, shadow(w1, dt), shadow(w2, dt), act, hmid, pre, None,
+                                           db1=zp.take(F), db2=zp.take(D))
+        dg2, dbe2 = zp.take(D), zp.take(D)
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy)
-        dbproj = ops.colsum(dx1)
+        dbproj = ops.colsum(dx1, out=zp.take(D))
         dwproj = _dw(dx1, attn)
         dattn = _dx(dx1, shadow(wproj, dt))
         dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse)
-        dbqkv = ops.colsum(dqkv) if ctx.has_qkv_bias else None
+        dbqkv = ops.colsum(dqkv, out=zp.take(3 * D)) if ctx.has_qkv_bias else None
         dwqkv = _dw(dqkv, h1)
         dh1 = _dx(dqkv, shadow(wqkv, dt))
-        dg1, dbe1 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        dg1, dbe1 = zp.take(D), zp.take(D)
         dx = ops.layernorm_bwd(dh1, x, mean1, rstd1, _f32(g1), dg1, dbe1, add=dx1)
         return dx, dg1, dbe1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbe2, dw1, db1, dw2, db2, None
 
@@ -280,19 +304,23 @@ class DisLayerFn(torch.autograd.Function):
         D = x.shape[1]
         dh = D // H
         dt = x.dtype
-        f32 = dict(device=x.device, dtype=torch.float32)
         dy = dy.contiguous()
-        dg2, dbe2 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        F = wi.shape[0]
+        ntab = (2 * N - 1) * 2 * D if tables is not None else 0
+        zp = _ZeroPool(x.device, D, D, D, D, D, F, D, 3 * D, ntab)
+        dg2, dbe2 = zp.take(D), zp.take(D)
         ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2)
-        da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, shadow(wi, dt), shadow(wout, dt), act, hmid, pre, ds2)
-        dg1, dbe1 = torch.zeros(D, **f32), torch.zeros(D, **f32)
+        da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, shadow(wi, dt), shadow(wout, dt), act, hmid, pre, ds2,
+                                              db1=zp.take(F), db2=zp.take(D))
+        dg1, dbe1 = zp.take(D), zp.take(D)
         ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1)
-        dbo = ops.colsum(ds1)
+        dbo = ops.colsum(ds1, out=zp.take(D))
         dwo = _dw(ds1, attn)
         dattn = _dx(ds1, shadow(wo, dt))
-        dqkv, dtab = _attn_bwd(qkv, B, N, H, dh, tables, scale, w, attn, dattn, lse)
+        dqkv, dtab = _attn_bwd(qkv, B, N, H, dh, tables, scale, w, attn, dattn, lse,
+                               dtab=zp.take(2 * N - 1, 2 * D) if tables is not None else None)
         wqkv = shadow((wq, wk, wv), dt)
-        dbqkv = ops.colsum(dqkv)
+        dbqkv = ops.colsum(dqkv, out=zp.take(3 * D))
         dwqkv = _dw(dqkv, x)
         dx = _dx(dqkv, wqkv, residual=ds1)
         dband = None
