@@ -195,8 +195,16 @@ def main():
         dom = max(agg, key=lambda k: agg[k][1])
         fl, sec, cnt = agg[dom]
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        # HBM-side bytes per launch of that kernel: measured with rocprofv3 --pmc in runs of their own
+        # (FETCH_SIZE and WRITE_SIZE cannot share a pass, and PMC runs cannot be nested in this one);
+        # the committed summary of those passes over this same command is read here.
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic.json')
+        if args.workload == 'dislai_b16' and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': fl / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': fl / sec / 1e12 / peak, 'traffic': None, 'launches': cnt,
+                    'frac': fl / sec / 1e12 / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/)',
+                    'launches': cnt,
                     'avg_launch_us': 1e6 * sec / cnt, 'avg_gflop_per_launch': fl / cnt / 1e9,
                     'share_of_step_time': sec / elapsed,
                     'all_gemm_tflops': sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12,

@@ -217,7 +217,7 @@ struct BandParams {
     long ldo;
     float* lse;
     const void* dout;
-    const float* delta;
+    float* delta;
     void *dq, *dk, *dv;
     long ld_d;
     int B, H, N, dh;

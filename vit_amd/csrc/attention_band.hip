@@ -32,7 +32,7 @@ struct BandParams {
     long ldo;
     float* lse;             // forward: written; backward: read
     const void* dout;
-    const float* delta;
+    float* delta;           // backward: delta_i = dO_i . O_i, WRITTEN here (read by attn_bwd_rel_kernel)
     void *dq, *dk, *dv;
     long ld_d;
     int B, H, N, dh;
@@ -212,15 +212,36 @@ __global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) 
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
     const T* dO = reinterpret_cast<const T*>(p.dout) + (long)b * N * p.ldo + h * dh;
+    const T* O = reinterpret_cast<const T*>(p.out) + (long)b * N * p.ldo + h * dh;
     const float* lse = p.lse + ((long)b * p.H + h) * N;
-    const float* delta = p.delta + ((long)b * p.H + h) * N;
+    float* delta = p.delta + ((long)b * p.H + h) * N;
 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
 
     stage_rows<T, DKB>(Qs, Q, p.ld, 0, NR, 0, N, dh, tid, 256);
     stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, 256);
-    stage_rows<T, DKB>(dOs, dO, p.ldo, 0, NR, 0, N, dh, tid, 256);
+    // dO rows go to LDS and, on the way, delta_i = dO_i . O_i is formed (the CPR lanes of a row
+    // each hold one 16-byte chunk of dO and of O): no separate delta kernel, no second read of dO.
+    for (int c = tid; c < NR * C::CPR; c += 256) {
+        const int r = c / C::CPR, ch = c - r * C::CPR;
+        const int d = ch * C::EPC;
+        bf16x8 v = {}, o = {};
+        if (r < N && d < dh) {
+            v = *reinterpret_cast<const bf16x8*>(dO + (long)r * p.ldo + d);
+            o = *reinterpret_cast<const bf16x8*>(O + (long)r * p.ldo + d);
+        }
+        *reinterpret_cast<bf16x8*>(dOs + r * ASTR + d) = v;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[e] * (float)o[e];
+#pragma unroll
+        for (int m = 1; m < C::CPR; m <<= 1) s += __shfl_xor(s, m, 64);
+        if (ch == 0) {
+            dls[r] = s;
+            if (r < N) delta[r] = s;
+        }
+    }
     if (BIAS) {
         const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
         const T* PQ = reinterpret_cast<const T*>(p.pq) + h * dh;
@@ -228,10 +249,7 @@ __global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) 
         stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
         stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
     }
-    for (int i = tid; i < NR; i += 256) {
-        lse2s[i] = i < N ? lse[i] * LOG2E : 0.f;
-        dls[i] = i < N ? delta[i] : 0.f;
-    }
+    for (int i = tid; i < NR; i += 256) lse2s[i] = i < N ? lse[i] * LOG2E : 0.f;
     __syncthreads();
 
     // ---- pass 1: key-stationary, dK^T / dV^T in registers --------------------------------------

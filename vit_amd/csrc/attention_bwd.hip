@@ -693,7 +693,7 @@ struct BandParams {
     long ldo;
     float* lse;
     const void* dout;
-    const float* delta;
+    float* delta;
     void *dq, *dk, *dv;
     long ld_d;
     int B, H, N, dh;
@@ -761,12 +761,8 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
 
     const long rows = (long)B * N;
     if (band_eligible(dtype, N, dh, pk != nullptr, band_w)) {
-        // whole-head kernels (attention_band.hip): dQ / dK / dV without atomics or accumulators
-        const long total = rows * H;
-        long blocks = (total + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(attn_delta_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, stream, (const __bf16*)out,
-                           (const __bf16*)dout, ldo, p.delta, B, H, N, dh);
+        // whole-head kernels (attention_band.hip): dQ / dK / dV without atomics or accumulators;
+        // delta is formed while dO is staged and left in the workspace for the table-gradient kernel
         BandParams bp = {};
         bp.q = q; bp.k = k; bp.v = v; bp.ld = ld;
         bp.pk = pk; bp.pq = pq; bp.ld_p = ld_p;
