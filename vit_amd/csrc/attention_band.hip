@@ -1,15 +1,19 @@
 // Whole-head attention kernels for short sequences (N <= 208 tokens, bf16, head dim <= 64): the
 // shapes of every ViT-224/16 configuration (197 tokens) and of the CIFAR plumbing config (65).
 //
-// One workgroup owns one (batch, head): Q / K / V / dO of the whole head are staged in LDS ONCE,
-// one barrier, and then the 4 waves run independently to the end -- no per-tile barriers, no
+// One workgroup (8 waves: two per SIMD, so one wave's LDS / MFMA latencies hide behind the other)
+// owns one (batch, head): the rows of the whole head are staged in LDS once per pass, and between
+// the few workgroup barriers the waves run independently -- no per-tile barriers, no
 // cross-workgroup reductions, no atomics, no fp32 workspace:
-//   forward : a wave owns query tiles qt = wave, wave+4, ...; lane = query (scores transposed),
+//   forward : a wave owns query tiles qt = wave, wave+8, ...; lane = query (scores transposed),
 //             online softmax in registers, O^T += V^T P^T with P taken straight from the score
 //             accumulators.
 //   backward: pass 1 is KEY-stationary (a wave owns key tiles; dK^T, dV^T stay in registers while
 //             it sweeps the live query tiles), pass 2 is QUERY-stationary (dQ^T in registers while
-//             it sweeps the live key tiles) over the SAME LDS images.  P is recomputed in both
+//             it sweeps the live key tiles).  Pass 1 needs Q and dO in LDS (its own K / V rows come
+//             from global memory), pass 2 needs K (its own Q / dO rows from global memory): K is
+//             staged over Q between the passes, so the kernel holds TWO row images, not three,
+//             which is what lets 8 waves' scratch fit in the 160 KiB.  P is recomputed in both
 //             passes: 38 instead of 26 MFMAs per tile buys the removal of every dQ atomic, of the
 //             fp32 dQ accumulator (memset + cast passes) and of all workgroup barriers.
 // The LAI band (|i-j| <= w) limits a tile row / column to 2*cmax+1 live tiles, cmax = (w+15)/16;
@@ -22,6 +26,8 @@
 namespace vitk {
 
 constexpr int BAND_DSLD = 20;   // floats per row of the 16 x 16 dS scratch tile
+constexpr int BAND_WAVES = 8;
+constexpr int BAND_THREADS = 64 * BAND_WAVES;
 
 struct BandParams {
     const void *q, *k, *v;
@@ -45,18 +51,18 @@ template <int DKB, bool BIAS> struct BandCfg {
     static constexpr int ASTR = C::ASTR;
     static size_t fwd_bytes(int NT, int cmax) {
         const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
-        return rows * ASTR * 2 + (size_t)4 * (BIAS ? 2 * SCR_FLOATS : 0) * 4;
+        return rows * ASTR * 2 + (size_t)BAND_WAVES * (BIAS ? 2 * SCR_FLOATS : 0) * 4;
     }
     static size_t bwd_bytes(int NT, int cmax) {
-        const size_t rows = 3 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
+        const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
         return rows * ASTR * 2 + (size_t)2 * (16 * NT + 16) * 4 +
-               (size_t)4 * ((BIAS ? 2 * SCR_FLOATS : 0) + 16 * BAND_DSLD) * 4;
+               (size_t)BAND_WAVES * ((BIAS ? 2 * SCR_FLOATS : 0) + 16 * BAND_DSLD) * 4;
     }
 };
 
 // ------------------------------------------------------------------------------------------ forward
 template <int DKB, bool BIAS>
-__global__ __launch_bounds__(256) void attn_fwd_band_kernel(const BandParams p) {
+__global__ __launch_bounds__(BAND_THREADS) void attn_fwd_band_kernel(const BandParams p) {
     using T = __bf16;
     using C = ACfg<T, DKB>;
     constexpr int ASTR = C::ASTR;
@@ -83,20 +89,20 @@ __global__ __launch_bounds__(256) void attn_fwd_band_kernel(const BandParams p) 
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
 
-    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, 256);
-    stage_rows<T, DKB>(Vs, V, p.ld, 0, NR, 0, N, dh, tid, 256);
+    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
+    stage_rows<T, DKB>(Vs, V, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
     if (BIAS) {
         const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
         const T* PQ = reinterpret_cast<const T*>(p.pq) + h * dh;
         const int r_lo = -16 * cmax - 15 + (N - 1);
-        stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
-        stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
+        stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, BAND_THREADS);
+        stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, BAND_THREADS);
     }
     __syncthreads();
 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
-    for (int qt = wave; qt < NT; qt += 4) {
+    for (int qt = wave; qt < NT; qt += BAND_WAVES) {
         const int qi0 = 16 * qt;
         const int qi = qi0 + li;
         Frag<T> qf[DKB];
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_fwd_band_kernel(const BandParams p) 
 
 // ----------------------------------------------------------------------------------------- backward
 template <int DKB, bool BIAS>
-__global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) {
+__global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandParams p) {
     using T = __bf16;
     using C = ACfg<T, DKB>;
     constexpr int ASTR = C::ASTR;
@@ -195,9 +201,9 @@ __global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) 
     const int WR = 32 * cmax + 32;
     const int h = blockIdx.x, b = blockIdx.y;
 
-    T* Qs = reinterpret_cast<T*>(smem);
-    T* Ks = Qs + NR * ASTR;
-    T* dOs = Ks + NR * ASTR;
+    T* Qs = reinterpret_cast<T*>(smem);   // pass 1: Q rows; pass 2: K rows
+    T* Ks = Qs;
+    T* dOs = Qs + NR * ASTR;
     T* Pks = dOs + NR * ASTR;
     T* Pqs = Pks + (BIAS ? WR * ASTR : 0);
     float* lse2s = reinterpret_cast<float*>(Pqs + (BIAS ? WR * ASTR : 0));
@@ -219,11 +225,10 @@ __global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
 
-    stage_rows<T, DKB>(Qs, Q, p.ld, 0, NR, 0, N, dh, tid, 256);
-    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, 256);
+    stage_rows<T, DKB>(Qs, Q, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
     // dO rows go to LDS and, on the way, delta_i = dO_i . O_i is formed (the CPR lanes of a row
     // each hold one 16-byte chunk of dO and of O): no separate delta kernel, no second read of dO.
-    for (int c = tid; c < NR * C::CPR; c += 256) {
+    for (int c = tid; c < NR * C::CPR; c += BAND_THREADS) {
         const int r = c / C::CPR, ch = c - r * C::CPR;
         const int d = ch * C::EPC;
         bf16x8 v = {}, o = {};
@@ -246,19 +251,19 @@ __global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) 
         const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
         const T* PQ = reinterpret_cast<const T*>(p.pq) + h * dh;
         const int r_lo = -16 * cmax - 15 + (N - 1);
-        stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
-        stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, 256);
+        stage_rows<T, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, BAND_THREADS);
+        stage_rows<T, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * N - 1, dh, tid, BAND_THREADS);
     }
-    for (int i = tid; i < NR; i += 256) lse2s[i] = i < N ? lse[i] * LOG2E : 0.f;
+    for (int i = tid; i < NR; i += BAND_THREADS) lse2s[i] = i < N ? lse[i] * LOG2E : 0.f;
     __syncthreads();
 
     // ---- pass 1: key-stationary, dK^T / dV^T in registers --------------------------------------
-    for (int kt = wave; kt < NT; kt += 4) {
+    for (int kt = wave; kt < NT; kt += BAND_WAVES) {
         const int kj0 = 16 * kt;
         Frag<T> kf[DKB], vf[DKB];
 #pragma unroll
         for (int kb = 0; kb < DKB; ++kb) {
-            row_frag<T, DKB>(kf[kb], Ks, kj0, kb, lane);
+            row_frag_global<T>(kf[kb], K, p.ld, kj0 + li, N, dh, kb, lane);
             row_frag_global<T>(vf[kb], V, p.ld, kj0 + li, N, dh, kb, lane);
         }
         f32x4 dkacc[ND], dvacc[ND];
@@ -346,15 +351,20 @@ __global__ __launch_bounds__(256) void attn_bwd_band_kernel(const BandParams p) 
         }
     }
 
+    // ---- K replaces Q in LDS -------------------------------------------------------------------
+    __syncthreads();
+    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
+    __syncthreads();
+
     // ---- pass 2: query-stationary, dQ^T in registers (lane = query) -----------------------------
-    for (int qt = wave; qt < NT; qt += 4) {
+    for (int qt = wave; qt < NT; qt += BAND_WAVES) {
         const int qi0 = 16 * qt;
         const int qi = qi0 + li;
         Frag<T> qf[DKB], dof[DKB];
 #pragma unroll
         for (int kb = 0; kb < DKB; ++kb) {
-            row_frag<T, DKB>(qf[kb], Qs, qi0, kb, lane);
-            row_frag<T, DKB>(dof[kb], dOs, qi0, kb, lane);
+            row_frag_global<T>(qf[kb], Q, p.ld, qi, N, dh, kb, lane);
+            row_frag_global<T>(dof[kb], dO, p.ldo, qi, N, dh, kb, lane);
         }
         const float lq = lse2s[qi], dq_delta = dls[qi];
         f32x4 dqacc[ND];
@@ -448,7 +458,7 @@ template <int DKB, bool BIAS> static void band_fwd_launch(const BandParams& p, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((attn_fwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((attn_fwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(BAND_THREADS), lds, st, p);
 }
 template <int DKB, bool BIAS> static void band_bwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
     const size_t lds = BandCfg<DKB, BIAS>::bwd_bytes(NT, cmax);
@@ -458,7 +468,7 @@ template <int DKB, bool BIAS> static void band_bwd_launch(const BandParams& p, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((attn_bwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((attn_bwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(BAND_THREADS), lds, st, p);
 }
 
 void band_launch(const BandParams& p, bool backward, hipStream_t st) {
