@@ -217,3 +217,30 @@ def test_gemm256_epilogues():
     want = torch.zeros(groups, per + 1, N, device='cuda')
     want[:, 1:] = lin.view(groups, per, N) + pos.float()[1:]
     assert relerr(tok.float().view(groups, per + 1, N), want) < tol
+
+
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False)])
+@pytest.mark.parametrize('M,N,K', [(4360, 4096, 192), (25216, 1024, 128)])
+def test_gemm256_persistent_items(ta, tb, M, N, K):
+    """More tiles than CUs: a workgroup of the persistent kernel walks several work items and the
+    K-tile pipeline crosses item boundaries (ragged last row of tiles included)."""
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), device='cuda').bfloat16()
+    b = torch.randn((N, K) if tb else (K, N), device='cuda').bfloat16()
+    A = a.float().t() if ta else a.float()
+    Bm = b.float().t() if tb else b.float()
+    ref = A @ Bm                                  # fp32 products of bf16 values, fp32 accumulation
+    out = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32)
+    assert relerr(out, ref) < 1e-5
+    if not ta:
+        bias = torch.randn(N, device='cuda')
+        res = torch.randn(M, N, device='cuda').bfloat16()
+        y = ops.gemm(a, b, trans_b=tb, bias=bias, residual=res)
+        assert relerr(y, ref + bias + res.float()) < 1.5e-2
+        pre = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        y = ops.gemm(a, b, trans_b=tb, bias=bias, act=ops.ACT_GELU, aux_out=pre)
+        assert relerr(pre, ref + bias) < 1.5e-2
+        assert relerr(y, torch.nn.functional.gelu(ref + bias)) < 1.5e-2
+        # every element, not only the max-norm: a misplaced tile would pass a max-norm check on noise-like data
+        assert (y.float() - torch.nn.functional.gelu(ref + bias)).abs().max().item() < 0.25
