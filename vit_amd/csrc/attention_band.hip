@@ -25,7 +25,7 @@
 
 namespace vitk {
 
-constexpr int BAND_DSLD = 20;   // floats per row of the 16 x 16 dS scratch tile
+constexpr int BAND_DS_FLOATS = 400;   // per wave: one zero-padded bf16 copy of a dS tile (X or Y layout, 1600 B)
 constexpr int BAND_WAVES = 8;
 constexpr int BAND_THREADS = 64 * BAND_WAVES;
 
@@ -56,7 +56,7 @@ template <int DKB, bool BIAS> struct BandCfg {
     static size_t bwd_bytes(int NT, int cmax) {
         const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
         return rows * ASTR * 2 + (size_t)2 * (16 * NT + 16) * 4 +
-               (size_t)BAND_WAVES * ((BIAS ? 2 * SCR_FLOATS : 0) + 16 * BAND_DSLD) * 4;
+               (size_t)BAND_WAVES * ((BIAS ? 2 * SCR_FLOATS : 0) + BAND_DS_FLOATS) * 4;
     }
 };
 
@@ -190,7 +190,6 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     using C = ACfg<T, DKB>;
     constexpr int ASTR = C::ASTR;
     constexpr int ND = 2 * DKB;
-    constexpr int DSLD = BAND_DSLD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -209,10 +208,10 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     float* lse2s = reinterpret_cast<float*>(Pqs + (BIAS ? WR * ASTR : 0));
     float* dls = lse2s + NR;
     float* scr = dls + NR;
-    constexpr int WSCR = (BIAS ? 2 * SCR_FLOATS : 0) + 16 * DSLD;
+    constexpr int WSCR = (BIAS ? 2 * SCR_FLOATS : 0) + BAND_DS_FLOATS;
     float* xs = scr + wave * WSCR;
     float* ys = xs + (BIAS ? SCR_FLOATS : 0);
-    float* dss = ys + (BIAS ? SCR_FLOATS : 0);
+    T* dsc = reinterpret_cast<T*>(ys + (BIAS ? SCR_FLOATS : 0));   // padded dS copy (attn_common.h)
 
     const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
@@ -258,6 +257,10 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     __syncthreads();
 
     // ---- pass 1: key-stationary, dK^T / dV^T in registers --------------------------------------
+    if (BIAS) {   // Y-layout copy: everything outside rows 15..30 stays zero for the whole pass
+        for (int i = lane; i < BAND_DS_FLOATS; i += 64) reinterpret_cast<float*>(dsc)[i] = 0.f;
+        wave_lds_sync();
+    }
     for (int kt = wave; kt < NT; kt += BAND_WAVES) {
         const int kj0 = 16 * kt;
         Frag<T> kf[DKB], vf[DKB];
@@ -302,15 +305,11 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                     }
                     if (BIAS) {   // dK^T[d][jj] += sum_t Pq^T[d][t] Sy[t][jj]
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dss[(4 * g + r) * DSLD + li] = dsv[r];
+                        for (int r = 0; r < 4; ++r) dsc[(15 + 4 * g + r) * DSY_LD + li] = (__bf16)dsv[r];
                         wave_lds_sync();
-                        Frag<T> sy;
+                        Frag<T> sy;   // Sy[t = 8g + e][jj = li] = dS[li + t - 15][li]
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int ii = li + 8 * g + e - 15;
-                            const float v = dss[min(max(ii, 0), 15) * DSLD + li];
-                            sy.v[e] = (__bf16)((ii >= 0 && ii < 16) ? v : 0.f);
-                        }
+                        for (int e = 0; e < 8; ++e) sy.v[e] = dsc[(li + 8 * g + e) * DSY_LD + li];
 #pragma unroll
                         for (int dt = 0; dt < ND; ++dt) {
                             Frag<T> a;
@@ -353,6 +352,9 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
 
     // ---- K replaces Q in LDS -------------------------------------------------------------------
     __syncthreads();
+    if (BIAS) {   // X-layout copy for pass 2: everything outside columns 16..31 stays zero
+        for (int i = lane; i < BAND_DS_FLOATS; i += 64) reinterpret_cast<float*>(dsc)[i] = 0.f;
+    }
     stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
     __syncthreads();
 
@@ -399,15 +401,12 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                         dsv[r] = pe * (dp[r] - dq_delta) * p.scale;
                     }
                     if (BIAS) {   // dQ^T[d][ii] += sum_t Pk^T[d][t] Sx[t][ii]
-                        *reinterpret_cast<f32x4*>(dss + li * DSLD + 4 * g) = dsv;
+                        *reinterpret_cast<bf16x4*>(dsc + li * DSX_LD + 16 + 4 * g) =
+                            bf16x4{(__bf16)dsv[0], (__bf16)dsv[1], (__bf16)dsv[2], (__bf16)dsv[3]};
                         wave_lds_sync();
-                        Frag<T> sx;
+                        Frag<T> sx;   // Sx[t = 8g + e][ii = li] = dS^T[li][li + 15 - t]
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int jj = li + 15 - 8 * g - e;
-                            const float v = dss[li * DSLD + min(max(jj, 0), 15)];
-                            sx.v[e] = (__bf16)((jj >= 0 && jj < 16) ? v : 0.f);
-                        }
+                        for (int e = 0; e < 8; ++e) sx.v[e] = dsc[li * (DSX_LD + 1) + 31 - 8 * g - e];
 #pragma unroll
                         for (int dt = 0; dt < ND; ++dt) {
                             Frag<T> a;

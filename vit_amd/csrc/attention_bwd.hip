@@ -397,7 +397,8 @@ template <typename T, int DKB> struct RelCfg {
     using C = ACfg<T, DKB>;
     // per wave: Q pair + K pair images (32 rows each), xs, ys, two dS tiles
     static constexpr size_t wave_bytes() {
-        return (size_t)64 * C::ASTR * sizeof(T) + (size_t)(2 * SCR_FLOATS + 2 * 16 * DSLD) * sizeof(float);
+        return (size_t)64 * C::ASTR * sizeof(T) + (size_t)2 * SCR_FLOATS * sizeof(float) +
+               (sizeof(T) == 2 ? (size_t)2 * DSXY_ELEMS * 2 : (size_t)2 * 16 * DSLD * sizeof(float));
     }
 };
 
@@ -450,10 +451,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_rel_kernel(const AttnBwdParam
     const int cmax = p.w >= 0 ? min((p.w + 15) / 16, NT - 1) : NT - 1;
     const bool banded = 2 * cmax + 1 < NT;
     const int nitems = banded ? 2 * cmax + 1 : NT;
-    const int item = blockIdx.x * 4 + wave;
-    const int h = blockIdx.y;
+    // (diagonal item, head) pairs are packed 4 to a workgroup: every wave of a workgroup has work
+    const int wid = blockIdx.x * 4 + wave;
+    const int h = wid / nitems;
+    const int item = wid - h * nitems;
     const int b_lo = blockIdx.z * p.bgroup, b_hi = min(p.B, b_lo + p.bgroup);
-    if (item >= nitems || b_lo >= b_hi) return;   // whole wave leaves; no workgroup barriers below
+    if (h >= p.H || b_lo >= b_hi) return;   // whole wave leaves; no workgroup barriers below
+    constexpr bool PADDED = sizeof(T) == 2;   // bf16: zero-padded dS copies (attn_common.h)
+    __bf16* dsx = reinterpret_cast<__bf16*>(dss);
+    if (PADDED) {
+        for (int i = lane; i < DSXY_ELEMS; i += 64) reinterpret_cast<float*>(dss)[i] = 0.f;   // 2 tiles x 1568 bf16
+        wave_lds_sync();
+    }
 
     const float sc2 = p.scale * 1.4426950408889634f;
     const T* PK = reinterpret_cast<const T*>(p.pk) + h * dh;
@@ -558,8 +567,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_rel_kernel(const AttnBwdParam
                         dsv[r] = pe * (dp[r] - dl[u][r]) * p.scale;
                     }
                 }
+                if (PADDED) {
+                    __bf16* X = dsx + u * DSXY_ELEMS;
+                    __bf16* Y = X + DSX_ELEMS;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[(4 * g + r) * DSLD + li] = dsv[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const __bf16 v = (__bf16)dsv[r];
+                        X[(4 * g + r) * DSX_LD + 16 + li] = v;
+                        Y[(15 + 4 * g + r) * DSY_LD + li] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[(4 * g + r) * DSLD + li] = dsv[r];
+                }
             }
             wave_lds_sync();
             // dPk[t][d] += sum_ii Sx[t][ii] Q[ii][d],  dPq[t][d] += sum_jj Sy[t][jj] K[jj][d]
@@ -571,15 +591,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_rel_kernel(const AttnBwdParam
                 for (int u = 0; u < 2; ++u) {
                     const int t = li + 16 * u;
                     Frag<T> ax, ay;
+                    if (PADDED) {
+                        const __bf16* X = dsx + (g >> 1) * DSXY_ELEMS;
+                        const __bf16* Y = X + DSX_ELEMS;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int l = lbase + e;
-                        const int jj = l + 15 - t;   // Sx[t][ii = l] = dS[l][l + 15 - t]
-                        const float vx = ds[l * DSLD + min(max(jj, 0), 15)];
-                        frag_set(ax, e, (jj >= 0 && jj < 16) ? vx : 0.f);
-                        const int ii = l + t - 15;   // Sy[t][jj = l] = dS[l + t - 15][l]
-                        const float vy = ds[min(max(ii, 0), 15) * DSLD + l];
-                        frag_set(ay, e, (ii >= 0 && ii < 16) ? vy : 0.f);
+                        for (int e = 0; e < 8; ++e) {
+                            const int l = lbase + e;
+                            frag_set(ax, e, (float)X[l * (DSX_LD + 1) + 31 - t]);   // dS[l][l + 15 - t]
+                            frag_set(ay, e, (float)Y[l * (DSY_LD + 1) + t * DSY_LD]);   // dS[l + t - 15][l]
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int l = lbase + e;
+                            const int jj = l + 15 - t;   // Sx[t][ii = l] = dS[l][l + 15 - t]
+                            const float vx = ds[l * DSLD + min(max(jj, 0), 15)];
+                            frag_set(ax, e, (jj >= 0 && jj < 16) ? vx : 0.f);
+                            const int ii = l + t - 15;   // Sy[t][jj = l] = dS[l + t - 15][l]
+                            const float vy = ds[min(max(ii, 0), 15) * DSLD + l];
+                            frag_set(ay, e, (ii >= 0 && ii < 16) ? vy : 0.f);
+                        }
                     }
 #pragma unroll
                     for (int dt = 0; dt < ND; ++dt) {
@@ -654,7 +685,7 @@ template <typename T, int DKB> static void rel_launch(const AttnBwdParams& p, in
     int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
     if (cmax > NT - 1) cmax = NT - 1;
     const int nitems = (2 * cmax + 1 < NT) ? 2 * cmax + 1 : NT;
-    dim3 grid((nitems + 3) / 4, p.H, zgroups);
+    dim3 grid((nitems * p.H + 3) / 4, 1, zgroups);
     hipLaunchKernelGGL((attn_bwd_rel_kernel<T, DKB>), grid, dim3(256), lds, st, p);
 }
 
@@ -753,7 +784,10 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
     int cmax = band_w >= 0 ? (band_w + 15) / 16 : NT - 1;
     if (cmax > NT - 1) cmax = NT - 1;
     const int nitems = (2 * cmax + 1 < NT) ? 2 * cmax + 1 : NT;
-    int zgroups = (3072 + nitems * H - 1) / (nitems * H);
+    // the kernel runs 2 workgroups (8 waves) per CU: aim at ONE full round of 512 workgroups of 4
+    // (item, head) waves each, so no wave slot idles behind a partial second round
+    const int blocks_per_group = (nitems * H + 3) / 4;
+    int zgroups = 512 / blocks_per_group;
     if (zgroups > B) zgroups = B;
     if (zgroups < 1) zgroups = 1;
     p.bgroup = (B + zgroups - 1) / zgroups;

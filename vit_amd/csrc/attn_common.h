@@ -24,6 +24,20 @@ namespace vitk {
 constexpr int SCR_LD = 36;                 // floats per scratch row (32 used + pad, keeps 16-B alignment)
 constexpr int SCR_FLOATS = 16 * SCR_LD;    // one 16 x 32 skew buffer
 
+// Zero-padded bf16 copies of a 16 x 16 dS tile for the skewed (Toeplitz) fragments of the
+// relative-table gradients.  Sx[t][i] = dS[i][i + 15 - t] and Sy[t][j] = dS[j + t - 15][j] run
+// along diagonals; with the tile embedded in zeros every out-of-range element reads 0 and the
+// 8 elements of a fragment sit at a constant stride, so a fragment is 8 plain 16-bit LDS reads
+// at immediate offsets -- no clamp / compare / select per element (those ~10 VALU per element
+// were 60 % of the table-gradient kernel's time).
+//   X copy: 16 rows x 48 columns, dS[i][j] at X[i * 48 + 16 + j]     (columns -16 .. 31)
+//   Y copy: 47 rows x 17 columns, dS[i][j] at Y[(15 + i) * 17 + j]   (rows -15 .. 31)
+constexpr int DSX_LD = 48;
+constexpr int DSX_ELEMS = 16 * DSX_LD;     // 768
+constexpr int DSY_LD = 17;
+constexpr int DSY_ELEMS = 47 * DSY_LD;     // 799
+constexpr int DSXY_ELEMS = 1568;           // X copy + Y copy of one tile, rounded up to 4 bytes
+
 template <typename T, int DKB> struct ACfg {
     static constexpr int EPC = 16 / sizeof(T);
     static constexpr int DP = 32 * DKB;                 // head dim padded to the MFMA K block
