@@ -25,7 +25,7 @@
 
 namespace vitk {
 
-constexpr int BAND_DS_FLOATS = 400;   // per wave: one zero-padded bf16 copy of a dS tile (X or Y layout, 1600 B)
+constexpr int BAND_DS_FLOATS = 800;   // per wave: one zero-padded fp32 copy of a dS tile (X or Y layout, attn_common.h)
 constexpr int BAND_WAVES = 8;
 constexpr int BAND_THREADS = 64 * BAND_WAVES;
 
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     constexpr int WSCR = (BIAS ? 2 * SCR_FLOATS : 0) + BAND_DS_FLOATS;
     float* xs = scr + wave * WSCR;
     float* ys = xs + (BIAS ? SCR_FLOATS : 0);
-    T* dsc = reinterpret_cast<T*>(ys + (BIAS ? SCR_FLOATS : 0));   // padded dS copy (attn_common.h)
+    float* dsc = ys + (BIAS ? SCR_FLOATS : 0);   // padded dS copy (attn_common.h)
 
     const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
 
     // ---- pass 1: key-stationary, dK^T / dV^T in registers --------------------------------------
     if (BIAS) {   // Y-layout copy: everything outside rows 15..30 stays zero for the whole pass
-        for (int i = lane; i < BAND_DS_FLOATS; i += 64) reinterpret_cast<float*>(dsc)[i] = 0.f;
+        for (int i = lane; i < BAND_DS_FLOATS; i += 64) dsc[i] = 0.f;
         wave_lds_sync();
     }
     for (int kt = wave; kt < NT; kt += BAND_WAVES) {
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                     }
                     if (BIAS) {   // dK^T[d][jj] += sum_t Pq^T[d][t] Sy[t][jj]
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dsc[(15 + 4 * g + r) * DSY_LD + li] = (__bf16)dsv[r];
+                        for (int r = 0; r < 4; ++r) dsc[(15 + 4 * g + r) * DSY_LD + li] = dsv[r];
                         wave_lds_sync();
                         Frag<T> sy;   // Sy[t = 8g + e][jj = li] = dS[li + t - 15][li]
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) sy.v[e] = dsc[(li + 8 * g + e) * DSY_LD + li];
+                        for (int e = 0; e < 8; ++e) sy.v[e] = (__bf16)dsc[(li + 8 * g + e) * DSY_LD + li];
 #pragma unroll
                         for (int dt = 0; dt < ND; ++dt) {
                             Frag<T> a;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     // ---- K replaces Q in LDS -------------------------------------------------------------------
     __syncthreads();
     if (BIAS) {   // X-layout copy for pass 2: everything outside columns 16..31 stays zero
-        for (int i = lane; i < BAND_DS_FLOATS; i += 64) reinterpret_cast<float*>(dsc)[i] = 0.f;
+        for (int i = lane; i < BAND_DS_FLOATS; i += 64) dsc[i] = 0.f;
     }
     stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
     __syncthreads();
@@ -401,12 +401,11 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                         dsv[r] = pe * (dp[r] - dq_delta) * p.scale;
                     }
                     if (BIAS) {   // dQ^T[d][ii] += sum_t Pk^T[d][t] Sx[t][ii]
-                        *reinterpret_cast<bf16x4*>(dsc + li * DSX_LD + 16 + 4 * g) =
-                            bf16x4{(__bf16)dsv[0], (__bf16)dsv[1], (__bf16)dsv[2], (__bf16)dsv[3]};
+                        *reinterpret_cast<f32x4*>(dsc + li * DSX_LD + 16 + 4 * g) = dsv;
                         wave_lds_sync();
                         Frag<T> sx;   // Sx[t = 8g + e][ii = li] = dS^T[li][li + 15 - t]
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) sx.v[e] = dsc[li * (DSX_LD + 1) + 31 - 8 * g - e];
+                        for (int e = 0; e < 8; ++e) sx.v[e] = (__bf16)dsc[li * (DSX_LD + 1) + 31 - 8 * g - e];
 #pragma unroll
                         for (int dt = 0; dt < ND; ++dt) {
                             Frag<T> a;
