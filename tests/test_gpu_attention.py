@@ -33,7 +33,7 @@ CASES = [(2, 65, 4, 32), (1, 197, 3, 64), (1, 197, 2, 80), (1, 130, 2, 128), (2,
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 @pytest.mark.parametrize('bias', [False, True], ids=['plain', 'dis'])
-@pytest.mark.parametrize('w', [-1, 8, 20])
+@pytest.mark.parametrize('w', [-1, 8, 20, 40])
 @pytest.mark.parametrize('B,N,H,dh', CASES)
 def test_attn_fwd(dtype, bias, w, B, N, H, dh):
     from vit_amd import ops
@@ -57,7 +57,7 @@ BWD_CASES = [(2, 65, 4, 32), (1, 197, 3, 64), (1, 197, 2, 80), (2, 16, 2, 64), (
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 @pytest.mark.parametrize('bias', [False, True], ids=['plain', 'dis'])
-@pytest.mark.parametrize('w', [-1, 8, 20])
+@pytest.mark.parametrize('w', [-1, 8, 20, 40])
 @pytest.mark.parametrize('B,N,H,dh', BWD_CASES)
 def test_attn_bwd(dtype, bias, w, B, N, H, dh):
     from vit_amd import ops
