@@ -223,6 +223,7 @@ struct BandParams {
     int B, H, N, dh;
     float scale;
     int w;
+    __bf16* ds_ws;
 };
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
 void band_launch(const BandParams& p, bool backward, hipStream_t st);

@@ -49,6 +49,7 @@ struct BandParams {
     int B, H, N, dh;
     float scale;
     int w;
+    __bf16* ds_ws;          // backward with the bias: dS tiles for the table-gradient kernel (attention_bwd.hip)
 };
 
 template <int DKB, bool BIAS> struct BandCfg {
@@ -359,6 +360,10 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                                 dsv[r] = pe * (dp[r] - dls[qi]) * p.scale;
                             }
                             if (BIAS) {   // dK^T[d][jj] += sum_t Pq^T[d][t] Sy[t][jj]
+                                if (p.ds_ws != nullptr)   // entry (b, h, c + cmax, kt): lane l holds dS[4 (l >> 4) + r][l & 15]
+                                    *reinterpret_cast<bf16x4*>(
+                                        p.ds_ws + ((((long)b * p.H + h) * (2 * grp.cmax + 1) + (qt - kt + grp.cmax)) * NT + kt) * 256 +
+                                        lane * 4) = bf16x4{(__bf16)dsv[0], (__bf16)dsv[1], (__bf16)dsv[2], (__bf16)dsv[3]};
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) dsc[(15 + 4 * g + r) * DSY_LD + li] = dsv[r];
                                 wave_lds_sync();

@@ -58,6 +58,7 @@ struct AttnBwdParams {
     float scale;
     int w;
     int bgroup;         // rel kernel: batches per wave
+    const __bf16* ds_ws; // whole-head path: dS tiles written by attn_bwd_band_kernel (else null)
 };
 
 __device__ __forceinline__ void frag_set(Frag<__bf16>& f, int e, float v) { f.v[e] = (__bf16)v; }
@@ -645,6 +646,161 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_rel_kernel(const AttnBwdParam
     }
 }
 
+// ------------------------------------------------------------------ dPk / dPq from stored dS tiles
+// Whole-head path: attn_bwd_band_kernel leaves every live 16 x 16 dS tile in a workspace
+// (bf16, entry (b, h, c + cmax, kt), 512 bytes, lane l holds dS[4 (l >> 4) + r][l & 15], r = 0..3),
+// so this kernel neither recomputes scores nor touches V / dO / LSE: per tile pair it reads the Q / K
+// rows and two dS tiles, builds the skewed fragments from zero-padded LDS copies and runs the
+// 16 table-gradient MFMAs.  Work decomposition and flush as attn_bwd_rel_kernel.
+template <int DKB> struct RelDsCfg {
+    using C = ACfg<__bf16, DKB>;
+    static constexpr size_t wave_bytes() { return (size_t)64 * C::ASTR * 2 + (size_t)2 * DSXY_ELEMS * 2; }
+};
+
+template <int DKB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_relds_kernel(const AttnBwdParams p) {
+    using T = __bf16;
+    using C = ACfg<T, DKB>;
+    constexpr int ASTR = C::ASTR;
+    constexpr int ND = 2 * DKB;
+    constexpr int CH = 32 * C::CPR / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    char* wbase = smem + wave * RelDsCfg<DKB>::wave_bytes();
+    T* Qw = reinterpret_cast<T*>(wbase);
+    T* Kw = Qw + 32 * ASTR;
+    T* dsx = Kw + 32 * ASTR;   // two tiles x (X copy, Y copy), attn_common.h
+
+    const int N = p.N, dh = p.dh;
+    const int NT = (N + 15) / 16;
+    const int cmax = p.w >= 0 ? min((p.w + 15) / 16, NT - 1) : NT - 1;
+    const int ndiag = 2 * cmax + 1;
+    const bool banded = ndiag < NT;
+    const int nitems = banded ? ndiag : NT;
+    const int wid = blockIdx.x * 4 + wave;
+    const int h = wid / nitems;
+    const int item = wid - h * nitems;
+    const int b_lo = blockIdx.z * p.bgroup, b_hi = min(p.B, b_lo + p.bgroup);
+    if (h >= p.H || b_lo >= b_hi) return;   // whole wave leaves; no workgroup barriers below
+    for (int i = lane; i < DSXY_ELEMS; i += 64) reinterpret_cast<float*>(dsx)[i] = 0.f;
+    wave_lds_sync();
+
+    for (int pass = 0; pass < (banded ? 1 : 2); ++pass) {
+        const int c = banded ? item - cmax : (pass == 0 ? item : item - NT);
+        if (!banded && pass == 1 && item == 0) break;
+        const int ac = c < 0 ? -c : c;
+        if (ac > cmax) continue;                         // diagonal outside the band: no tiles stored
+        const int ntile = NT - ac;
+        const int npair = (ntile + 1) / 2;
+        const int ibase = 16 * (c > 0 ? c : 0), jbase = 16 * (c < 0 ? -c : 0);
+        const int ilim = min(N, ibase + 16 * ntile), jlim = min(N, jbase + 16 * ntile);
+        const int R0 = 16 * c - 15 + (N - 1);            // table row of t = 0
+        const int kt0 = jbase >> 4;
+
+        f32x4 apk[2][ND], apq[2][ND];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                apk[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                apq[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+
+        const int total = (b_hi - b_lo) * npair;
+        u32x4 pq_[CH], pk_[CH];
+        bf16x4 pds[2];
+        auto fetch = [&](int it) {
+            const int b = b_lo + it / npair, m = 2 * (it % npair);
+            const int i0 = ibase + 16 * m, j0 = jbase + 16 * m;
+            const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
+            const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc) {
+                const int idx = lane + 64 * cc;
+                const int r = idx / C::CPR, d = (idx - r * C::CPR) * C::EPC;
+                pq_[cc] = u32x4{0, 0, 0, 0};
+                pk_[cc] = u32x4{0, 0, 0, 0};
+                if (i0 + r < ilim && d < dh) pq_[cc] = *reinterpret_cast<const u32x4*>(Q + (long)(i0 + r) * p.ld + d);
+                if (j0 + r < jlim && d < dh) pk_[cc] = *reinterpret_cast<const u32x4*>(K + (long)(j0 + r) * p.ld + d);
+            }
+            const __bf16* ws = p.ds_ws + ((((long)b * p.H + h) * ndiag + (c + cmax)) * NT + kt0 + m) * 256 + lane * 4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pds[u] = bf16x4{};
+                if (m + u < ntile) pds[u] = *reinterpret_cast<const bf16x4*>(ws + u * 256);
+            }
+        };
+        fetch(0);
+        for (int it = 0; it < total; ++it) {
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc) {
+                const int idx = lane + 64 * cc;
+                const int r = idx / C::CPR, d = (idx - r * C::CPR) * C::EPC;
+                *reinterpret_cast<u32x4*>(Qw + r * ASTR + d) = pq_[cc];
+                *reinterpret_cast<u32x4*>(Kw + r * ASTR + d) = pk_[cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                __bf16* X = dsx + u * DSXY_ELEMS;
+                __bf16* Y = X + DSX_ELEMS;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    X[(4 * g + r) * DSX_LD + 16 + li] = pds[u][r];
+                    Y[(15 + 4 * g + r) * DSY_LD + li] = pds[u][r];
+                }
+            }
+            if (it + 1 < total) fetch(it + 1);
+            wave_lds_sync();
+            // dPk[t][d] += sum_ii Sx[t][ii] Q[ii][d],  dPq[t][d] += sum_jj Sy[t][jj] K[jj][d]
+            // K dimension = the pair's 32 rows: k = 8g+e -> tile (g >> 1), local row 8(g&1)+e
+            {
+                const __bf16* X = dsx + (g >> 1) * DSXY_ELEMS;
+                const __bf16* Y = X + DSX_ELEMS;
+                const int lbase = 8 * (g & 1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = li + 16 * u;
+                    Frag<T> ax, ay;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int l = lbase + e;
+                        ax.v[e] = X[l * (DSX_LD + 1) + 31 - t];        // Sx[t][l] = dS[l][l + 15 - t]
+                        ay.v[e] = Y[l * (DSY_LD + 1) + t * DSY_LD];    // Sy[t][l] = dS[l + t - 15][l]
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) {
+                        Frag<T> bq, bk;
+                        col_frag(bq, Qw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
+                        col_frag(bk, Kw, ASTR, 8 * g, 8 * g + 4, 16 * dt, lane);
+                        apk[u][dt] = mma(ax, bq, apk[u][dt]);
+                        apq[u][dt] = mma(ay, bk, apq[u][dt]);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+        // flush: acc[u][dt][r] = dP*[t = 16u+4g+r][d = 16dt+li]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * u + 4 * g + r;
+                const int row = R0 + t;
+                if (t < 31 && row >= 0 && row < 2 * N - 1) {
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) {
+                        const int d = 16 * dt + li;
+                        if (d < dh) {
+                            atomicAdd(p.dpk + (long)row * p.ld_dp + h * dh + d, apk[u][dt][r]);
+                            atomicAdd(p.dpq + (long)row * p.ld_dp + h * dh + d, apq[u][dt][r]);
+                        }
+                    }
+                }
+            }
+    }
+}
+
 // fp32 accumulator rows -> T rows (bf16 path's dQ)
 __global__ void cast_rows_kernel(const float* __restrict__ src, long lds_, __bf16* __restrict__ dst, long ldd, long rows,
                                  int cols) {
@@ -689,6 +845,22 @@ template <typename T, int DKB> static void rel_launch(const AttnBwdParams& p, in
     hipLaunchKernelGGL((attn_bwd_rel_kernel<T, DKB>), grid, dim3(256), lds, st, p);
 }
 
+template <int DKB> static void relds_launch(const AttnBwdParams& p, int zgroups, hipStream_t st) {
+    const size_t lds = 4 * RelDsCfg<DKB>::wave_bytes();
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_relds_kernel<DKB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr = true;
+    }
+    const int NT = (p.N + 15) / 16;
+    int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
+    if (cmax > NT - 1) cmax = NT - 1;
+    const int nitems = (2 * cmax + 1 < NT) ? 2 * cmax + 1 : NT;
+    dim3 grid((nitems * p.H + 3) / 4, 1, zgroups);
+    hipLaunchKernelGGL((attn_bwd_relds_kernel<DKB>), grid, dim3(256), lds, st, p);
+}
+
 template <typename T, int KTW> static void bwd_dispatch(const AttnBwdParams& p, int zgroups, hipStream_t st) {
     const int dkb = (p.dh + 31) / 32;
     const bool bias = p.pk != nullptr;
@@ -730,6 +902,7 @@ struct BandParams {
     int B, H, N, dh;
     float scale;
     int w;
+    __bf16* ds_ws;
 };
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
 void band_launch(const BandParams& p, bool backward, hipStream_t st);
@@ -739,11 +912,21 @@ using namespace vitk;
 
 static bool b16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Bytes of fp32 workspace vitk_attn_bwd needs: delta [B*H*N] (+ the dQ accumulator for bf16).
+// Bytes of workspace vitk_attn_bwd needs: delta [B*H*N] fp32, then the larger of the fp32 dQ
+// accumulator of the generic bf16 path and the dS tiles of the whole-head path (worst case: every
+// tile diagonal live, 512 bytes per 16 x 16 tile).
 extern "C" long vitk_attn_bwd_workspace_bytes(int dtype, int B, int H, int N, int dh) {
-    long n = ((long)B * H * N + 63) / 64 * 64;
-    if (dtype == VITK_BF16) n += (long)B * N * H * dh;
-    return n * 4;
+    long n = ((long)B * H * N + 63) / 64 * 64 * 4;
+    if (dtype == VITK_BF16) {
+        long extra = (long)B * N * H * dh * 4;
+        if (band_eligible(dtype, N, dh, true, -1)) {
+            const long NT = (N + 15) / 16;
+            const long ds = (long)B * H * (2 * NT - 1) * NT * 512;
+            if (ds > extra) extra = ds;
+        }
+        n += extra;
+    }
+    return n;
 }
 
 extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void* q, const void* k, const void* v,
@@ -805,11 +988,14 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
         bp.dq = dq; bp.dk = dk; bp.dv = dv; bp.ld_d = ld_d;
         bp.B = B; bp.H = H; bp.N = N; bp.dh = dh;
         bp.scale = scale; bp.w = band_w;
+        // with the bias, pass 1 also leaves its dS tiles behind delta for the table-gradient kernel
+        bp.ds_ws = pk ? reinterpret_cast<__bf16*>(p.delta + ((long)B * H * N + 63) / 64 * 64) : nullptr;
+        p.ds_ws = bp.ds_ws;
         band_launch(bp, true, stream);
         if (pk) {
             const int dkb = (dh + 31) / 32;
-            if (dkb == 1) rel_launch<__bf16, 1>(p, zgroups, stream);
-            else rel_launch<__bf16, 2>(p, zgroups, stream);
+            if (dkb == 1) relds_launch<1>(p, zgroups, stream);
+            else relds_launch<2>(p, zgroups, stream);
         }
         VITK_CHECK_LAUNCH("vitk_attn_bwd");
         return VITK_OK;
