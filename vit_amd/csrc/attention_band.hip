@@ -9,13 +9,13 @@
 //             online softmax in registers, O^T += V^T P^T with P taken straight from the score
 //             accumulators.
 //   backward: pass 1 is KEY-stationary (a wave owns key tiles; dK^T, dV^T stay in registers while
-//             it sweeps the live query tiles), pass 2 is QUERY-stationary (dQ^T in registers while
-//             it sweeps the live key tiles).  Pass 1 needs Q and dO in LDS (its own K / V rows come
-//             from global memory), pass 2 needs K (its own Q / dO rows from global memory): K is
-//             staged over Q between the passes, so the kernel holds TWO row images, not three,
-//             which is what lets 8 waves' scratch fit in the 160 KiB.  P is recomputed in both
-//             passes: 38 instead of 26 MFMAs per tile buys the removal of every dQ atomic, of the
-//             fp32 dQ accumulator (memset + cast passes) and of all workgroup barriers.
+//             it sweeps the live query tiles) and leaves every 16 x 16 dS tile (bf16) in a
+//             workspace; pass 2 is QUERY-stationary (dQ^T in registers) and only reads those tiles
+//             back -- no second recompute of P -- as does the table-gradient kernel
+//             (attn_bwd_relds_kernel, attention_bwd.hip).  Pass 1 needs Q and dO in LDS (its own
+//             K / V rows come from global memory), pass 2 needs K: K is staged over Q between the
+//             passes, so the kernel holds TWO row images, not three, which is what lets 8 waves'
+//             scratch fit in the 160 KiB.  No dQ atomics, no fp32 dQ accumulator.
 // The LAI band (|i-j| <= w) limits a tile row / column to 2*cmax+1 live tile diagonals,
 // cmax = (w+15)/16 (NT-1 when unmasked).  With the disentangled bias the live diagonals are walked
 // in GROUPS of up to 5 (c_lo .. c_lo+4): the 96 relative-table rows a group can touch are staged,
@@ -23,7 +23,6 @@
 // softmax state / gradient accumulators stay in registers across groups -- and the next group's
 // rows replace them (two workgroup barriers per group).  Every LAI stage of the reference
 // (w = 8..20) is a single group; the unmasked disentangled stage of 197 tokens is five.
-// dPk / dPq stay with attn_bwd_rel_kernel (attention_bwd.hip).
 #include "attn_common.h"
 
 namespace vitk {
@@ -270,6 +269,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     const T* O = reinterpret_cast<const T*>(p.out) + (long)b * N * p.ldo + h * dh;
     const float* lse = p.lse + ((long)b * p.H + h) * N;
     float* delta = p.delta + ((long)b * p.H + h) * N;
+    __bf16* ds_head = p.ds_ws + ((long)b * p.H + h) * (2 * grp.cmax + 1) * NT * 256;   // this head's dS tiles
 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
@@ -359,11 +359,11 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                                 pv[r] = pe;
                                 dsv[r] = pe * (dp[r] - dls[qi]) * p.scale;
                             }
+                            // the dS tile is kept for pass 2 and for the table-gradient kernel:
+                            // entry (b, h, c + cmax, kt), lane l holds dS[4 (l >> 4) + r][l & 15]
+                            *reinterpret_cast<bf16x4*>(ds_head + ((long)(qt - kt + grp.cmax) * NT + kt) * 256 + lane * 4) =
+                                bf16x4{(__bf16)dsv[0], (__bf16)dsv[1], (__bf16)dsv[2], (__bf16)dsv[3]};
                             if (BIAS) {   // dK^T[d][jj] += sum_t Pq^T[d][t] Sy[t][jj]
-                                if (p.ds_ws != nullptr)   // entry (b, h, c + cmax, kt): lane l holds dS[4 (l >> 4) + r][l & 15]
-                                    *reinterpret_cast<bf16x4*>(
-                                        p.ds_ws + ((((long)b * p.H + h) * (2 * grp.cmax + 1) + (qt - kt + grp.cmax)) * NT + kt) * 256 +
-                                        lane * 4) = bf16x4{(__bf16)dsv[0], (__bf16)dsv[1], (__bf16)dsv[2], (__bf16)dsv[3]};
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) dsc[(15 + 4 * g + r) * DSY_LD + li] = dsv[r];
                                 wave_lds_sync();
@@ -423,23 +423,15 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
 
     // ---- pass 2: query-stationary, dQ^T of the wave's query tiles in registers (lane = query) ----
+    // dS is NOT recomputed: pass 1 left every live tile in the workspace (same workgroup, visible
+    // after the barriers above); a lane reads its 4 keys of the transposed tile as 4 bf16 loads.
     {
-        Frag<T> qf[BAND_TPW][DKB], dof[BAND_TPW][DKB];
         f32x4 dqacc[BAND_TPW][ND];
-        float lq[BAND_TPW], dq_delta[BAND_TPW];
 #pragma unroll
-        for (int s = 0; s < BAND_TPW; ++s) {
-            const int qi = 16 * (wave + BAND_WAVES * s) + li;   // < NR: lse2s / dls hold zeros past N
-#pragma unroll
-            for (int kb = 0; kb < DKB; ++kb) {
-                row_frag_global<T>(qf[s][kb], Q, p.ld, qi, N, dh, kb, lane);
-                row_frag_global<T>(dof[s][kb], dO, p.ldo, qi, N, dh, kb, lane);
-            }
-            lq[s] = qi < NR ? lse2s[qi] : 0.f;
-            dq_delta[s] = qi < NR ? dls[qi] : 0.f;
+        for (int s = 0; s < BAND_TPW; ++s)
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt) dqacc[s][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        const int tr_off = ((li >> 2) * 16 + 4 * g) * 4 + (li & 3);   // dS[query li][key 4g + r] at tr_off + 4 r
         for (int gi = 0; gi < grp.ngroups; ++gi) {
             const int c_lo = grp.c_lo(gi), c_hi = grp.c_hi(gi);
             if (BIAS && grp.ngroups > 1) {   // a single group's rows are still in place from pass 1
@@ -452,7 +444,6 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                 const int qt = wave + BAND_WAVES * s;
                 if (qt >= NT) continue;
                 const int qi0 = 16 * qt;
-                const int qi = qi0 + li;
                 const int klo = max(0, qt - c_hi), khi = min(NT - 1, qt - c_lo);
                 for (int ka = klo; ka <= khi; ka += 2) {
                     f32x4 dst[2];
@@ -461,32 +452,16 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                         const int kt = ka + u;
                         f32x4 dsv = {0.f, 0.f, 0.f, 0.f};
                         if (kt <= khi) {
-                            const int kj0 = 16 * kt;
-                            const int rel = qi0 - kj0 - 16 * c_lo;
-                            Frag<T> kf[DKB], vf[DKB];
+                            const __bf16* e = ds_head + ((long)(qt - kt + grp.cmax) * NT + kt) * 256 + tr_off;
 #pragma unroll
-                            for (int kb = 0; kb < DKB; ++kb) {
-                                row_frag<T, DKB>(kf[kb], Ks, kj0, kb, lane);
-                                row_frag_global<T>(vf[kb], V, p.ld, kj0 + li, N, dh, kb, lane);
-                            }
-                            // transposed tiles: result[r] = X[query li][key 4g + r]
-                            const f32x4 raw = score_tile<T, DKB, BIAS, true>(qf[s], kf, Pks, Pqs, rel, xs, ys, lane);
-                            f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int kb = 0; kb < DKB; ++kb) dp = mma(vf[kb], dof[s][kb], dp);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int kj = kj0 + 4 * g + r;
-                                const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
-                                const float pe = ok ? exp2f(raw[r] * sc2 - lq[s]) : 0.f;
-                                dsv[r] = pe * (dp[r] - dq_delta[s]) * p.scale;
-                            }
+                            for (int r = 0; r < 4; ++r) dsv[r] = (float)e[4 * r];
                             if (BIAS) {   // dQ^T[d][ii] += sum_t Pk^T[d][t] Sx[t][ii]
+                                const int rel = qi0 - 16 * kt - 16 * c_lo;
                                 *reinterpret_cast<f32x4*>(dsc + li * DSX_LD + 16 + 4 * g) = dsv;
                                 wave_lds_sync();
                                 Frag<T> sx;   // Sx[t = 8g + e][ii = li] = dS^T[li][li + 15 - t]
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) sx.v[e] = (__bf16)dsc[li * (DSX_LD + 1) + 31 - 8 * g - e];
+                                for (int ee = 0; ee < 8; ++ee) sx.v[ee] = (__bf16)dsc[li * (DSX_LD + 1) + 31 - 8 * g - ee];
 #pragma unroll
                                 for (int dt = 0; dt < ND; ++dt) {
                                     Frag<T> a;

@@ -988,8 +988,8 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
         bp.dq = dq; bp.dk = dk; bp.dv = dv; bp.ld_d = ld_d;
         bp.B = B; bp.H = H; bp.N = N; bp.dh = dh;
         bp.scale = scale; bp.w = band_w;
-        // with the bias, pass 1 also leaves its dS tiles behind delta for the table-gradient kernel
-        bp.ds_ws = pk ? reinterpret_cast<__bf16*>(p.delta + ((long)B * H * N + 63) / 64 * 64) : nullptr;
+        // pass 1 leaves its dS tiles behind delta: for pass 2 and for the table-gradient kernel
+        bp.ds_ws = reinterpret_cast<__bf16*>(p.delta + ((long)B * H * N + 63) / 64 * 64);
         p.ds_ws = bp.ds_ws;
         band_launch(bp, true, stream);
         if (pk) {
