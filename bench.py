@@ -118,6 +118,8 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=1)
     ap.add_argument('--cpu-layers', type=int, default=24)
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--force-reducer', action='store_true',
+                    help='diagnostic: run the gradient reducer (flat slabs, hooks, all-reduce) even at world size 1')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -131,8 +133,11 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
 
     variant, preset, img, patch, classes, dbatch = WORKLOADS[args.workload]
@@ -146,7 +151,7 @@ def main():
                       mask_epochs=MASK_EPOCHS if 'lai' in variant else None, dtype=dtype, device=dev)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, fused=True)
     reducer = None
-    if world > 1:
+    if world > 1 or args.force_reducer:
         from vit_amd.ddp import GradReducer
         reducer = GradReducer(net, bucket_mb=args.bucket_mb)
     epoch = STAGE_EPOCH[args.band] if takes_epoch(net) else None
@@ -231,7 +236,7 @@ def main():
             'loss': loss_val, 'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         dist.barrier()
         dist.destroy_process_group()
 

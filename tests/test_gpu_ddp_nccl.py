@@ -1,0 +1,43 @@
+"""The gradient reducer on the GPU over RCCL (backend "nccl"), world size 1 (the box has one GPU):
+the flat-slab / hook / all-reduce path must give the same training trajectory as no reducer.
+The world-2 behaviour is rehearsed on CPU in tests/test_ddp_gloo.py."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reducer_nccl_world1_matches_plain():
+    from vit_amd.ddp import GradReducer
+    from vit_amd.train import build_model, train_step
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + os.getpid() % 300), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        kw = dict(img_size=32, patch_size=4, num_classes=10, dtype=torch.bfloat16, depth=2)
+        nets = []
+        for _ in range(2):
+            torch.manual_seed(0)
+            nets.append(build_model('disentangled_lai_attention', 'cifar', **kw))
+        nets[1].load_state_dict(nets[0].state_dict())
+        x = torch.randn(16, 3, 32, 32, device='cuda')
+        y = torch.randint(0, 10, (16,), device='cuda')
+        opts = [torch.optim.AdamW(n.parameters(), lr=1e-3) for n in nets]
+        red = GradReducer(nets[1], bucket_mb=1)
+        losses = [[], []]
+        for step in range(3):
+            losses[0].append(float(train_step(nets[0], opts[0], x, y, 0)))
+            losses[1].append(float(train_step(nets[1], opts[1], x, y, 0, reducer=red)))
+        assert len(red.buckets) > 1
+        # atomics make the two runs differ in the last bits only
+        for a, b in zip(*losses):
+            assert abs(a - b) < 2e-2 * max(1.0, abs(a)), (losses)
+        unused = [n for n, p in nets[1].named_parameters() if p.grad is None]
+        assert sorted(unused) == sorted(n for n, p in nets[0].named_parameters() if p.grad is None)
+        for (n, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+            assert torch.allclose(p.float(), q.float(), atol=5e-3, rtol=5e-2), n
+    finally:
+        dist.destroy_process_group()
