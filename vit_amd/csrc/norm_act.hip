@@ -102,8 +102,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ add];  dgamma += sum dy*xhat;
 // dbeta += sum dy.  Each wave walks rows with a grid stride and keeps its dgamma/dbeta partial
 // sums in registers; waves combine through LDS and issue one fp32 atomic per column per block.
+// 8 waves per block: the row loop is latency-bound (16 waves per CU stream twice the rows), while
+// the cost of the final cross-block reduction grows with the number of BLOCKS, not waves.
+constexpr int LN_BWD_WAVES = 8;
+constexpr int LN_BWD_THREADS = 64 * LN_BWD_WAVES;
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long lddy,
+__global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* __restrict__ dy, long lddy,
                                                             const T* __restrict__ x, long ldx,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunk = D >> 3;
-    for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * D; i += LN_BWD_THREADS) red[i] = 0.f;
     __syncthreads();
     float dg[NV][8], db[NV][8], g[NV][8];
 #pragma unroll
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
         if (c < nchunk) load8<float>(g[i], gamma + c * 8);
     }
-    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    for (long row = (long)blockIdx.x * LN_BWD_WAVES + wave; row < rows; row += (long)gridDim.x * LN_BWD_WAVES) {
         const float mu = mean[row], rs = rstd[row];
         float vdy[NV][8], xh[NV][8];
         float s1 = 0.f, s2 = 0.f;
@@ -183,9 +187,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += 256) {
-        if (dgamma) atomicAdd(&dgamma[i], red[i]);
-        if (dbeta) atomicAdd(&dbeta[i], red[D + i]);
+    // every block finishes at about the same time: rotate each block's starting column so that
+    // concurrent blocks add to different addresses (same-address atomics serialise in the L2)
+    const int rot = (blockIdx.x * 256) % D;
+    for (int i = threadIdx.x; i < D; i += LN_BWD_THREADS) {
+        int c = i + rot;
+        if (c >= D) c -= D;
+        if (dgamma) atomicAdd(&dgamma[c], red[c]);
+        if (dbeta) atomicAdd(&dbeta[c], red[D + c]);
     }
 }
 
@@ -365,14 +374,14 @@ extern "C" int vitk_layernorm_fwd(int dtype, int rows, int D, const void* x, lon
 }
 
 template <typename T>
-static void ln_bwd_dispatch(int rows, int D, const T* dy, long lddy, const T* x, long ldx, const float* mean,
+    if (grid > 512) grid = 512;
                             const float* rstd, const float* gamma, const T* add, long ldadd, T* dx, long lddx,
                             float* dgamma, float* dbeta, hipStream_t st) {
     const int nv = (D / 8 + 63) / 64;
     int grid = (rows + 3) / 4;
-    if (grid > 512) grid = 512;
+    if (grid > 384) grid = 384;
     const size_t lds = 2 * (size_t)D * sizeof(float);
-#define L(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(256), lds, st, dy, lddy, x, ldx, mean, rstd, gamma, add, ldadd, dx, lddx, dgamma, dbeta, rows, D)
+#define L(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(LN_BWD_THREADS), lds, st, dy, lddy, x, ldx, mean, rstd, gamma, add, ldadd, dx, lddx, dgamma, dbeta, rows, D)
     if (nv <= 1) L(1); else if (nv <= 2) L(2); else L(4);
 #undef L
 }
