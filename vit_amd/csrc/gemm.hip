@@ -279,7 +279,10 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
                   al(residual, 16) && ((!aux_in && !aux_out) || ld_aux % 8 == 0) && (!residual || ldr % 8 == 0);
     p.alpha = alpha;
     const bool linear_f32 = c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out && grp_rows == 0;
-    const bool big = dtype == VITK_BF16 && gemm256_eligible(p, transA, transB);
+    // The 256-tile kernel runs one workgroup per CU: a problem with few tiles and no split-K (bf16 output,
+    // e.g. the 393-row relative-table GEMMs) would leave most of the chip idle -> finer 128 x 128 tiles.
+    const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const bool big = dtype == VITK_BF16 && gemm256_eligible(p, transA, transB) && (linear_f32 || tiles256 >= 48);
     const int tile = big ? 256 : BM;
     const int bk = big ? 64 : 128 / esz;
     const int ksteps = (K + bk - 1) / bk;
