@@ -166,14 +166,16 @@ class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
         self.layer_norm_out = nn.LayerNorm(d_model)
         self.dropout_out = nn.Dropout(dropout)
 
-    def forward2d(self, x2, band, B, N, epoch):
-        """x2 [B*N, D] and band [2N-1, D] (or None) in compute dtype -> [B*N, D]; one autograd node."""
+    def forward2d(self, x2, band, B, N, epoch, x_ext=False):
+        """x2 [B*N, D] and band [2N-1, D] (or None) in compute dtype -> [B*N, D]; one autograd node.
+        ``x_ext``: x2 is the output of the previous layer's forward2d with the same band (its buffer
+        already has the rows the relative table rides in: functional.DisLayerFn)."""
         a = self.dis_attn
         _check_p0(self, a.dropout.p, self.dropout_AttnOut.p, self.dropout_out.p)
         if self.layer_norm_AttnOut.eps != self.layer_norm_out.eps:
             raise NotImplementedError('DisentangledEncoderLayer: the two LayerNorms must share eps')
         cfg = (B, N, a.num_attention_heads, self.layer_norm_out.eps, a.scale(), a._width(0 if epoch is None else epoch),
-               'gelu')
+               'gelu', bool(x_ext and band is not None))
         q, k, v = a.query_proj, a.key_proj, a.value_proj
         return VF.DisLayerFn.apply(x2, band, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
                                    self.dense_AttnOut.weight, self.dense_AttnOut.bias,
@@ -229,10 +231,10 @@ class DisentangledEncoder(ComputeDtypeMixin, nn.Module):
         rel = self.get_rel_embedding()
         dt = self.compute_dtype
         band = None
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
             if band is None:
                 band = layer.dis_attn.band_for(rel, N, dt)   # identical for every (cloned) layer
-            x2 = layer.forward2d(x2, band, B, N, epoch)
+            x2 = layer.forward2d(x2, band, B, N, epoch, x_ext=i > 0)
         return x2
 
     def forward(self, src, pos=None, epoch=None):

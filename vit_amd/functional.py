@@ -149,13 +149,14 @@ def _attn_fwd(qkv, B, N, H, dh, tables, scale, w):
     return ops.attn_fwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w)
 
 
-def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None):
+def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None, dqkv=None):
     """Returns dqkv [B*N, 3D] and (for tables) fp32 dtables [2N-1, 2D] (dPq | dPk); ``dtab``: a
     zeroed buffer to accumulate into."""
     D = H * dh
     ld = qkv.stride(0)
     q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-    dqkv = torch.empty(B * N, 3 * D, device=qkv.device, dtype=qkv.dtype)
+    if dqkv is None:
+        dqkv = torch.empty(B * N, 3 * D, device=qkv.device, dtype=qkv.dtype)
     dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
     pq = pk = dpq = dpk = None
     ld_p = 0
@@ -268,67 +269,106 @@ class PreLNBlockFn(torch.autograd.Function):
         return dx, dg1, dbe1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbe2, dw1, db1, dw2, db2, None
 
 
+def _tail_rows(M1, R):
+    """Rows appended to a [M1, D] token matrix for R relative-table rows: R plus zero rows up to
+    the next multiple of 64 of the total (the K dimension of the dW GEMM)."""
+    return R + (-(M1 + R)) % 64
+
+
 class DisLayerFn(torch.autograd.Function):
     """DisentangledEncoderLayer.forward (disentangled_transformer.py:228-246): post-LN block whose
     attention adds the c2p / p2c terms from relative rows projected with the content q/k
     projections (share_att_key, :270,373-377).  ``band`` = the 2N-1 reachable rows of the
-    LayerNormed relative table (row r <-> i - j = r - (N-1)), already in compute dtype."""
+    LayerNormed relative table (row r <-> i - j = r - (N-1)), already in compute dtype.
+
+    The table rows ride along as EXTRA ROWS of the token matrix: x_ext = [x ; band ; 0] goes through
+    the qkv GEMM once (the tail of its output is (Pq | Pk | unused)), and in backward
+    dqkv_ext = [dqkv ; (dPq | dPk | 0)] gives the bias / weight gradients of the shared projections
+    and dband from the same three GEMMs as the tokens -- no 393-row GEMMs, extra column sums or
+    accumulate passes.  cfg[7] (``x_ext``) says that x is the head of a buffer that already has
+    the tail rows allocated (the previous layer's output), so nothing is copied."""
 
     @staticmethod
     def forward(ctx, x, band, wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wi, bi, wout, bout, g2, be2, cfg):
-        B, N, H, eps, scale, w, act = cfg
-        D = x.shape[1]
+        B, N, H, eps, scale, w, act = cfg[:7]
+        x_is_ext = len(cfg) > 7 and cfg[7]
+        M1, D = x.shape
         dh = D // H
         dt = x.dtype
         wqkv = shadow((wq, wk, wv), dt)
         bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
-        qkv = ops.gemm(x, wqkv, bias=bqkv)
         tables = None
         if band is not None:
-            tables = ops.gemm(band, wqkv[:2 * D], bias=bqkv[:2 * D])      # [2N-1, 2D] = (Pq | Pk)
+            R = band.shape[0]
+            ME = M1 + _tail_rows(M1, R)
+            if x_is_ext and (x.storage_offset() != 0 or not x.is_contiguous()
+                             or x.untyped_storage().nbytes() < ME * D * x.element_size()):
+                raise ValueError('DisLayerFn: x_ext set but x is not the head of a [%d, %d] buffer' % (ME, D))
+            if x_is_ext:
+                x_ext = torch.empty(0, device=x.device, dtype=dt).set_(x.untyped_storage(), 0, (ME, D), (D, 1))
+            else:
+                x_ext = torch.empty(ME, D, device=x.device, dtype=dt)
+                x_ext[:M1].copy_(x)
+            x_ext[M1:M1 + R].copy_(band)
+            x_ext[M1 + R:].zero_()
+            x = x_ext[:M1]
+            qkv_ext = ops.gemm(x_ext, wqkv, bias=bqkv)
+            qkv = qkv_ext[:M1]
+            tables = qkv_ext[M1:M1 + R, :2 * D]                   # (Pq | Pk), row stride 3 D
+            y_ext = torch.empty(ME, D, device=x.device, dtype=dt)
+        else:
+            x_ext, qkv_ext = x, ops.gemm(x, wqkv, bias=bqkv)
+            qkv = qkv_ext
+            y_ext = torch.empty(M1, D, device=x.device, dtype=dt)
         attn, lse = _attn_fwd(qkv, B, N, H, dh, tables, scale, w)
         s1 = ops.gemm(attn, shadow(wo, dt), bias=_f32(bo), residual=x)
         a, mean1, rstd1 = ops.layernorm_fwd(s1, _f32(g1), _f32(be1), eps)
         s2, hmid, pre = _mlp_fwd(a, shadow(wi, dt), _f32(bi), shadow(wout, dt), _f32(bout), act, a)
-        y, mean2, rstd2 = ops.layernorm_fwd(s2, _f32(g2), _f32(be2), eps)
-        ctx.save_for_backward(x, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv, tables, attn, lse, s1, mean1, rstd1,
+        y, mean2, rstd2 = ops.layernorm_fwd(s2, _f32(g2), _f32(be2), eps, out=y_ext[:M1])
+        ctx.save_for_backward(x_ext, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv_ext, attn, lse, s1, mean1, rstd1,
                               a, hmid, pre, s2, mean2, rstd2)
         ctx.cfg = cfg
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv, tables, attn, lse, s1, mean1, rstd1, a, hmid, pre, s2,
+        (x_ext, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv_ext, attn, lse, s1, mean1, rstd1, a, hmid, pre, s2,
          mean2, rstd2) = ctx.saved_tensors
-        B, N, H, eps, scale, w, act = ctx.cfg
-        D = x.shape[1]
+        B, N, H, eps, scale, w, act = ctx.cfg[:7]
+        M1 = B * N
+        ME, D = x_ext.shape
         dh = D // H
-        dt = x.dtype
+        dt = x_ext.dtype
         dy = dy.contiguous()
         F = wi.shape[0]
-        ntab = (2 * N - 1) * 2 * D if tables is not None else 0
-        zp = _ZeroPool(x.device, D, D, D, D, D, F, D, 3 * D, ntab)
+        R = band.shape[0] if band is not None else 0
+        zp = _ZeroPool(x_ext.device, D, D, D, D, D, F, D, 3 * D, R * 2 * D)
         dg2, dbe2 = zp.take(D), zp.take(D)
         ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2)
         da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, shadow(wi, dt), shadow(wout, dt), act, hmid, pre, ds2,
                                               db1=zp.take(F), db2=zp.take(D))
         dg1, dbe1 = zp.take(D), zp.take(D)
-        ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1)
+        ds1_ext = torch.empty(ME, D, device=x_ext.device, dtype=dt)
+        ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1])
         dbo = ops.colsum(ds1, out=zp.take(D))
         dwo = _dw(ds1, attn)
         dattn = _dx(ds1, shadow(wo, dt))
-        dqkv, dtab = _attn_bwd(qkv, B, N, H, dh, tables, scale, w, attn, dattn, lse,
-                               dtab=zp.take(2 * N - 1, 2 * D) if tables is not None else None)
-        wqkv = shadow((wq, wk, wv), dt)
-        dbqkv = ops.colsum(dqkv, out=zp.take(3 * D))
-        dwqkv = _dw(dqkv, x)
-        dx = _dx(dqkv, wqkv, residual=ds1)
-        dband = None
+        dqkv_ext = torch.empty(ME, 3 * D, device=x_ext.device, dtype=dt)
+        tables = dtab = None
         if band is not None:
-            dtab_t = dtab.to(dt)
-            ops.colsum(dtab_t, out=dbqkv[:2 * D])
-            ops.gemm(dtab_t, band, trans_a=True, trans_b=False, out=dwqkv[:2 * D], accumulate=True)
-            dband = _dx(dtab_t, wqkv[:2 * D])
+            tables = qkv_ext[M1:M1 + R, :2 * D]
+            dtab = zp.take(R, 2 * D)
+            ds1_ext[M1:].zero_()
+            dqkv_ext[M1:].zero_()
+        _attn_bwd(qkv_ext[:M1], B, N, H, dh, tables, scale, w, attn, dattn, lse, dtab=dtab, dqkv=dqkv_ext[:M1])
+        if band is not None:
+            dqkv_ext[M1:M1 + R, :2 * D].copy_(dtab)               # (dPq | dPk) in compute dtype
+        wqkv = shadow((wq, wk, wv), dt)
+        dbqkv = ops.colsum(dqkv_ext, out=zp.take(3 * D))
+        dwqkv = _dw(dqkv_ext, x_ext)
+        dx_ext = _dx(dqkv_ext, wqkv, residual=ds1_ext)
+        dx = dx_ext[:M1]
+        dband = dx_ext[M1:M1 + R] if band is not None else None
         dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
         dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
         return (dx, dband, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg1, dbe1, dwi, dbi, dwout, dbout, dg2, dbe2,

@@ -111,10 +111,12 @@ def gemm(a, b, *, trans_a=False, trans_b=True, out=None, out_dtype=None, bias=No
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
-    _req_cuda(x, gamma, beta)
+def layernorm_fwd(x, gamma, beta, eps, want_stats=True, out=None):
+    _req_cuda(x, gamma, beta, out)
     px, rows, D, ldx = _rows2d(x, 'layernorm x')
-    y = torch.empty(rows, D, device=x.device, dtype=x.dtype)
+    y = out if out is not None else torch.empty(rows, D, device=x.device, dtype=x.dtype)
+    if y.shape != (rows, D) or y.dtype != x.dtype or not y.is_contiguous():
+        raise ValueError('layernorm_fwd: out must be a contiguous [rows, D] tensor of the input dtype')
     mean = torch.empty(rows, device=x.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if want_stats else None
     st = lib().vitk_layernorm_fwd(_dt(x), rows, D, px, ldx, gamma.data_ptr(), beta.data_ptr(), float(eps),
@@ -123,12 +125,14 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, add=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, add=None, out=None):
     """Returns dx (+ add).  dgamma / dbeta (fp32 [D]) are accumulated into."""
-    _req_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, add)
+    _req_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, add, out)
     pdy, rows, D, lddy = _rows2d(dy, 'layernorm dy')
     px, _, _, ldx = _rows2d(x, 'layernorm x')
-    dx = torch.empty(rows, D, device=x.device, dtype=x.dtype)
+    dx = out if out is not None else torch.empty(rows, D, device=x.device, dtype=x.dtype)
+    if dx.shape != (rows, D) or dx.dtype != x.dtype or not dx.is_contiguous():
+        raise ValueError('layernorm_bwd: out must be a contiguous [rows, D] tensor of the input dtype')
     padd, ldadd = 0, 0
     if add is not None:
         padd, ra, ca, ldadd = _rows2d(add, 'layernorm add')
