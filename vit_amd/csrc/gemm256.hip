@@ -352,16 +352,20 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
 #undef VITK_PICK_ROW
 
 // ------------------------------------------------------------------------------------ kernel
-// Work item = (K split, output tile).
+// Work item = (K split, output tile).  The XCD remap runs over the whole (split, tile) list, split
+// major: the 32 items one XCD has in flight are a compact block of tiles of ONE K range (8 x 4
+// tiles read 12 operand panels through that XCD's L2; spread over the splits they read 36, and
+// the split-K weight-gradient GEMMs ran into the fabric bandwidth: 3.6 TB/s of L2 misses).
 struct Item256 {
     int m0, n0, ks0, ks1, split;
 };
 __device__ __forceinline__ Item256 item256(const GemmParams& p, int item) {
     const int ntiles = p.tiles_m * p.tiles_n;
     Item256 it;
+    item = gemm_xcd_remap(item, ntiles * p.splitk);
     it.split = item / ntiles;
     int tile_m, tile_n;
-    gemm_tile_of(item - it.split * ntiles, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    gemm_grouped_tile(item - it.split * ntiles, p.tiles_m, p.tiles_n, tile_m, tile_n);
     it.m0 = tile_m * T256;
     it.n0 = tile_n * T256;
     const int ksteps_total = p.K / 64;

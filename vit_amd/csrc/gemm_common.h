@@ -232,14 +232,15 @@ __device__ __forceinline__ void gemm_epilogue8_fast(const GemmParams& p, int m, 
     }
 }
 
-// XCD-aware (bijective) remap of a linear tile id, then groups of GROUP_M row panels: workgroups
-// that share an A row panel / B column panel run on one XCD (private L2) back to back.
-__device__ __forceinline__ void gemm_tile_of(int bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
-    const int ntiles = tiles_m * tiles_n;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
+// XCD-aware (bijective) remap of a linear id in [0, n): workgroup i runs on XCD i & 7 (grids are
+// multiples of 8), so XCD x gets the x-th contiguous eighth of the ids.
+__device__ __forceinline__ int gemm_xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// Tile order in groups of GROUP_M row panels: consecutive ids share an A row panel / B column panel.
+__device__ __forceinline__ void gemm_grouped_tile(int bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
     constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * tiles_n;
     const int grp = bid / per_group;
@@ -248,6 +249,11 @@ __device__ __forceinline__ void gemm_tile_of(int bid, int tiles_m, int tiles_n, 
     const int in_grp = bid - grp * per_group;
     tile_m = first_m + in_grp % gsize;
     tile_n = in_grp / gsize;
+}
+
+// Both: workgroups that share a panel run on one XCD (private L2) back to back.
+__device__ __forceinline__ void gemm_tile_of(int bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    gemm_grouped_tile(gemm_xcd_remap(bid, tiles_m * tiles_n), tiles_m, tiles_n, tile_m, tile_n);
 }
 
 }  // namespace vitk
