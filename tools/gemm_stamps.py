@@ -3,6 +3,8 @@ import sys, os
 os.environ['VITK_GEMM_DEBUG'] = '32'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from vit_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_stamps', 'libvitk.so')   # gemm256.hip built with -DVITK_GEMM_STAMPS
 from vit_amd import ops
 for (name, m, n, k, tb) in [('sq4096 NT', 4096, 4096, 4096, True), ('qkv NT', 128 * 197, 3072, 1024, True), ('sq4096 NN', 4096, 4096, 4096, False)]:
     a = torch.randn(m, k, device='cuda').bfloat16()

@@ -32,6 +32,13 @@ constexpr int BAND_WAVES = 8;
 constexpr int BAND_THREADS = 64 * BAND_WAVES;
 constexpr int BAND_GC = 2;            // half width of a diagonal group with the bias: 2 * 2 + 1 = 5 diagonals, 96 table rows
 constexpr int BAND_TPW = 2;           // tiles a wave can own: NT <= 13 tiles over 8 waves
+// The forward holds two row images (K, V), not three: 16 waves' scratch fits, every wave owns ONE query
+// tile (the critical path is one tile's sweep, not two) and four waves per SIMD hide each other's
+// LDS / MFMA / exp latencies.
+constexpr int BAND_FWD_WAVES = 16;
+constexpr int BAND_FWD_THREADS = 64 * BAND_FWD_WAVES;
+constexpr int BAND_FWD_TPW = 1;
+static_assert(BAND_FWD_WAVES * BAND_FWD_TPW >= 13 && BAND_WAVES * BAND_TPW >= 13, "N <= 208 is 13 tiles");
 
 struct BandParams {
     const void *q, *k, *v;
@@ -57,7 +64,8 @@ template <int DKB, bool BIAS> struct BandCfg {
     static size_t fwd_bytes(int NT, int cmax) {
         cmax = cmax < BAND_GC ? cmax : BAND_GC;
         const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
-        return rows * ASTR * 2 + (size_t)BAND_WAVES * (BIAS ? 2 * SCR_FLOATS : 0) * 4;
+        const int sw = NT < BAND_FWD_WAVES ? NT : BAND_FWD_WAVES;   // waves that own a tile (the rest only stage)
+        return rows * ASTR * 2 + (size_t)sw * (BIAS ? 2 * SCR_FLOATS : 0) * 4;
     }
     static size_t bwd_bytes(int NT, int cmax) {
         cmax = cmax < BAND_GC ? cmax : BAND_GC;
@@ -84,16 +92,16 @@ struct BandGroups {
 // relative-table rows of one diagonal group -> LDS (row 0 <-> i - j = 16 c_lo - 15)
 template <int DKB>
 __device__ __forceinline__ void band_stage_tables(const BandParams& p, __bf16* Pks, __bf16* Pqs, int WR, int c_lo, int h,
-                                                  int tid) {
+                                                  int tid, int nthreads) {
     const __bf16* PK = reinterpret_cast<const __bf16*>(p.pk) + h * p.dh;
     const __bf16* PQ = reinterpret_cast<const __bf16*>(p.pq) + h * p.dh;
     const int r_lo = 16 * c_lo - 15 + (p.N - 1);
-    stage_rows<__bf16, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, BAND_THREADS);
-    stage_rows<__bf16, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, BAND_THREADS);
+    stage_rows<__bf16, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, nthreads);
+    stage_rows<__bf16, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, nthreads);
 }
 
 template <int DKB, bool BIAS>
-__global__ __launch_bounds__(BAND_THREADS) void attn_fwd_band_kernel(const BandParams p) {
+__global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const BandParams p) {
     using T = __bf16;
     using C = ACfg<T, DKB>;
     constexpr int ASTR = C::ASTR;
@@ -120,18 +128,18 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_fwd_band_kernel(const BandP
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
 
-    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
-    stage_rows<T, DKB>(Vs, V, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
+    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_FWD_THREADS);
+    stage_rows<T, DKB>(Vs, V, p.ld, 0, NR, 0, N, dh, tid, BAND_FWD_THREADS);
 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
-    // per-tile state of the (at most BAND_TPW) query tiles this wave owns
-    Frag<T> qf[BAND_TPW][DKB];
-    float m2[BAND_TPW], lsum[BAND_TPW];
-    f32x4 oacc[BAND_TPW][ND];
+    // per-tile state of the (at most BAND_FWD_TPW) query tiles this wave owns
+    Frag<T> qf[BAND_FWD_TPW][DKB];
+    float m2[BAND_FWD_TPW], lsum[BAND_FWD_TPW];
+    f32x4 oacc[BAND_FWD_TPW][ND];
 #pragma unroll
-    for (int s = 0; s < BAND_TPW; ++s) {
-        const int qi = 16 * (wave + BAND_WAVES * s) + li;
+    for (int s = 0; s < BAND_FWD_TPW; ++s) {
+        const int qi = 16 * (wave + BAND_FWD_WAVES * s) + li;
 #pragma unroll
         for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(qf[s][kb], Q, p.ld, qi, N, dh, kb, lane);
         m2[s] = -INFINITY;
@@ -144,12 +152,12 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_fwd_band_kernel(const BandP
         const int c_lo = grp.c_lo(gi), c_hi = grp.c_hi(gi);
         if (BIAS) {
             if (gi > 0) __syncthreads();                      // every wave is done with the previous group's rows
-            band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid);
+            band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_FWD_THREADS);
         }
         if (BIAS || gi == 0) __syncthreads();
 #pragma unroll
-        for (int s = 0; s < BAND_TPW; ++s) {
-            const int qt = wave + BAND_WAVES * s;
+        for (int s = 0; s < BAND_FWD_TPW; ++s) {
+            const int qt = wave + BAND_FWD_WAVES * s;
             if (qt >= NT) continue;
             const int qi0 = 16 * qt;
             const int qi = qi0 + li;
@@ -211,8 +219,8 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_fwd_band_kernel(const BandP
     }
 
 #pragma unroll
-    for (int s = 0; s < BAND_TPW; ++s) {
-        const int qi = 16 * (wave + BAND_WAVES * s) + li;
+    for (int s = 0; s < BAND_FWD_TPW; ++s) {
+        const int qi = 16 * (wave + BAND_FWD_WAVES * s) + li;
         float ls = lsum[s];
         ls += __shfl_xor(ls, 16, 64);
         ls += __shfl_xor(ls, 32, 64);
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
             const int c_lo = grp.c_lo(gi), c_hi = grp.c_hi(gi);
             if (BIAS) {
                 if (gi > 0) __syncthreads();
-                band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid);
+                band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_THREADS);
             }
             if (BIAS || gi == 0) __syncthreads();
 #pragma unroll
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
             const int c_lo = grp.c_lo(gi), c_hi = grp.c_hi(gi);
             if (BIAS && grp.ngroups > 1) {   // a single group's rows are still in place from pass 1
                 if (gi > 0) __syncthreads();
-                band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid);
+                band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_THREADS);
             }
             if ((BIAS && grp.ngroups > 1) || gi == 0) __syncthreads();
 #pragma unroll
@@ -519,7 +527,7 @@ template <int DKB, bool BIAS> static void band_fwd_launch(const BandParams& p, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((attn_fwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(BAND_THREADS), lds, st, p);
+    hipLaunchKernelGGL((attn_fwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(BAND_FWD_THREADS), lds, st, p);
 }
 template <int DKB, bool BIAS> static void band_bwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
     const size_t lds = BandCfg<DKB, BIAS>::bwd_bytes(NT, cmax);

@@ -476,6 +476,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         stage_offsets<B_KM, true>(offb, p.ldb, pf.n0, p.N, wave, lane);
     };
 
+#ifdef VITK_GEMM_STAMPS
+    // timeline mode (VITK_GEMM_DEBUG=64): [0] kernel start, then per item r < 10: main loop start / end, epilogue end
+    const bool tl = (p.debug & 64) && lane == 0 && (wave & 3) == 0;
+    long* tls = reinterpret_cast<long*>(p.aux_out) + blockIdx.x * 64 + wm * 32;
+    int tl_r = 0;
+    if (tl) tls[0] = __builtin_amdgcn_s_memtime();
+#endif
     issue_slot(0);
     issue_slot(1);
     issue_slot(2);
@@ -497,6 +504,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int next = item + gridDim.x;
         const Item256 me = it;
+#ifdef VITK_GEMM_STAMPS
+        if (tl && tl_r < 10) tls[1 + 3 * tl_r] = __builtin_amdgcn_s_memtime();
+#endif
 
         for (int ks = me.ks0; ks < me.ks1; ++ks) {
             const char* la = smem + cur * STAGE256;
@@ -560,8 +570,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             long* stamps = reinterpret_cast<long*>(p.aux_out) + blockIdx.x * 64 + wm * 32;
 #endif
             VITK_STAMP(21);
+#ifdef VITK_GEMM_STAMPS
+            if (tl && tl_r < 10) tls[2 + 3 * tl_r] = __builtin_amdgcn_s_memtime();
+#endif
             epilogue256<TC>(p, acc, wl, me.m0 + wm * 128, me.n0 + wn * 64, me.split, lane);
             VITK_STAMP(22);
+#ifdef VITK_GEMM_STAMPS
+            if (tl && tl_r < 10) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                tls[3 + 3 * tl_r] = __builtin_amdgcn_s_memtime();
+                ++tl_r;
+            }
+#endif
         }
         if (next >= nitems) break;
         item = next;
