@@ -60,10 +60,13 @@ int vitk_layernorm_fwd(int dtype, int rows, int D, const void* x, long ldx, cons
                        const float* beta, float eps, void* y, long ldy, float* mean, float* rstd,
                        void* stream);
 /* dx = LN'(dy) [+ add] (add = the residual branch's gradient); dgamma / dbeta [D] fp32 are
- * ACCUMULATED into (zero them for a fresh sum). */
+ * ACCUMULATED into (zero them for a fresh sum).  dxsum (may be NULL): [D] fp32, += column sums of
+ * dx = the bias gradient of the Linear feeding a post-LN residual (dense_AttnOut / dense_out,
+ * disentangled_transformer.py:187-196), accumulated like dgamma. */
 int vitk_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, const void* x, long ldx,
                        const float* mean, const float* rstd, const float* gamma, const void* add,
-                       long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, void* stream);
+                       long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* dxsum,
+                       void* stream);
 
 /* out[n] += sum_m X[m][n]: bias gradients of every nn.Linear above (autograd of addmm). */
 int vitk_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, void* stream);

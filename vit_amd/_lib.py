@@ -25,7 +25,7 @@ _SIGNATURES = {
     'vitk_layernorm_fwd': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_vp, c_float, c_vp, c_long,
                             c_vp, c_vp, c_vp], c_int),
     'vitk_layernorm_bwd': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp,
-                            c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp], c_int),
+                            c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp, c_vp], c_int),
     'vitk_colsum': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_vp], c_int),
     'vitk_cast': ([c_int, c_long, c_vp, c_vp, c_vp], c_int),
     'vitk_patchify': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp], c_int),

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 
 // ------------------------------------------------------------------ LayerNorm backward
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ add];  dgamma += sum dy*xhat;
-// dbeta += sum dy.  Each wave walks rows with a grid stride and keeps its dgamma/dbeta partial
+// dbeta += sum dy;  optionally dxsum += column sums of dx (the bias gradient of the Linear that
+// produced the LayerNorm's input in a post-LN block -- saves a separate pass over dx).  Each wave walks rows with a grid stride and keeps its dgamma/dbeta partial
 // sums in registers; waves combine through LDS and issue one fp32 atomic per column per block.
 // 8 waves per block, one block per CU: the cost of the final cross-block reduction grows with the
 // number of BLOCKS, not waves (16 waves per block spill: 72 us against 52).
@@ -115,15 +116,16 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
                                                             const T* __restrict__ add, long ldadd,
                                                             T* __restrict__ dx, long lddx,
                                                             float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int rows, int D) {
+                                                            float* __restrict__ dbeta,
+                                                            float* __restrict__ dxsum, int rows, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw);  // [2][D]
+    float* red = reinterpret_cast<float*>(smem_raw);  // [3][D]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunk = D >> 3;
-    for (int i = threadIdx.x; i < 2 * D; i += LN_BWD_THREADS) red[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * D; i += LN_BWD_THREADS) red[i] = 0.f;
     __syncthreads();
-    float dg[NV][8], db[NV][8], g[NV][8];
+    float dg[NV][8], db[NV][8], g[NV][8], ds[NV][8];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
         for (int e = 0; e < 8; ++e) {
             dg[i][e] = 0.f;
             db[i][e] = 0.f;
+            ds[i][e] = 0.f;
             g[i][e] = 0.f;
         }
         if (c < nchunk) load8<float>(g[i], gamma + c * 8);
@@ -171,6 +174,10 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += a[e];
                 }
+                if (dxsum) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ds[i][e] += o[e];
+                }
                 store8<T>(dx + row * lddx + c * 8, o);
             }
         }
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
             for (int e = 0; e < 8; ++e) {
                 atomicAdd(&red[c * 8 + e], dg[i][e]);
                 atomicAdd(&red[D + c * 8 + e], db[i][e]);
+                if (dxsum) atomicAdd(&red[2 * D + c * 8 + e], ds[i][e]);
             }
         }
     }
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
         if (c >= D) c -= D;
         if (dgamma) atomicAdd(&dgamma[c], red[c]);
         if (dbeta) atomicAdd(&dbeta[c], red[D + c]);
+        if (dxsum) atomicAdd(&dxsum[c], red[2 * D + c]);
     }
 }
 
@@ -352,7 +361,7 @@ static int ln_fwd_dispatch(int rows, int D, const T* x, long ldx, const float* g
     const int nv = (D / 8 + 63) / 64;
     const int grid = rows < 4 * 2048 ? (rows + 3) / 4 : 2048;
 #define L(NV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, rows, D)
-    if (nv <= 1) L(1); else if (nv <= 2) L(2); else L(4);
+    if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 3) L(3); else L(4);
 #undef L
     return 0;
 }
@@ -376,7 +385,7 @@ extern "C" int vitk_layernorm_fwd(int dtype, int rows, int D, const void* x, lon
 template <typename T>
 static void ln_bwd_dispatch(int rows, int D, const T* dy, long lddy, const T* x, long ldx, const float* mean,
                             const float* rstd, const float* gamma, const T* add, long ldadd, T* dx, long lddx,
-                            float* dgamma, float* dbeta, hipStream_t st) {
+                            float* dgamma, float* dbeta, float* dxsum, hipStream_t st) {
     const int nv = (D / 8 + 63) / 64;
     int grid = (rows + LN_BWD_WAVES - 1) / LN_BWD_WAVES;
     // one block per CU: the rows are dealt out evenly over the blocks, so a CU holding two blocks
@@ -391,16 +400,16 @@ static void ln_bwd_dispatch(int rows, int D, const T* dy, long lddy, const T* x,
         cus = n;
     }
     if (grid > cus) grid = cus;
-    const size_t lds = 2 * (size_t)D * sizeof(float);
-#define L(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(LN_BWD_THREADS), lds, st, dy, lddy, x, ldx, mean, rstd, gamma, add, ldadd, dx, lddx, dgamma, dbeta, rows, D)
-    if (nv <= 1) L(1); else if (nv <= 2) L(2); else L(4);
+    const size_t lds = 3 * (size_t)D * sizeof(float);
+#define L(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(LN_BWD_THREADS), lds, st, dy, lddy, x, ldx, mean, rstd, gamma, add, ldadd, dx, lddx, dgamma, dbeta, dxsum, rows, D)
+    if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 3) L(3); else L(4);
 #undef L
 }
 
-// dgamma / dbeta are ACCUMULATED into (fp32, caller zeroes them when a fresh sum is wanted).
+// dgamma / dbeta / dxsum are ACCUMULATED into (fp32, caller zeroes them when a fresh sum is wanted).
 extern "C" int vitk_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, const void* x, long ldx,
                                   const float* mean, const float* rstd, const float* gamma, const void* add,
-                                  long ldadd, void* dx, long lddx, float* dgamma, float* dbeta,
+                                  long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, float* dxsum,
                                   hipStream_t stream) {
     VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "vitk_layernorm_bwd: bad dtype");
     VITK_CHECK_ARG(D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXV, "vitk_layernorm_bwd: D=%d must be a multiple of 8, <= 2048", D);
@@ -411,10 +420,10 @@ extern "C" int vitk_layernorm_bwd(int dtype, int rows, int D, const void* dy, lo
     if (rows == 0) return VITK_OK;
     if (dtype == VITK_BF16)
         ln_bwd_dispatch<__bf16>(rows, D, (const __bf16*)dy, lddy, (const __bf16*)x, ldx, mean, rstd, gamma,
-                                (const __bf16*)add, ldadd, (__bf16*)dx, lddx, dgamma, dbeta, stream);
+                                (const __bf16*)add, ldadd, (__bf16*)dx, lddx, dgamma, dbeta, dxsum, stream);
     else
         ln_bwd_dispatch<float>(rows, D, (const float*)dy, lddy, (const float*)x, ldx, mean, rstd, gamma,
-                               (const float*)add, ldadd, (float*)dx, lddx, dgamma, dbeta, stream);
+                               (const float*)add, ldadd, (float*)dx, lddx, dgamma, dbeta, dxsum, stream);
     VITK_CHECK_LAUNCH("vitk_layernorm_bwd");
     return VITK_OK;
 }

@@ -207,10 +207,12 @@ def _mlp_fwd(x, w1, b1, w2, b2, act, residual):
     return y, hmid, pre
 
 
-def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad, db1=None, db2=None):
-    """Returns dx (+ residual_grad), dW1, db1, dW2, db2 (db1 / db2: zeroed accumulators, optional)."""
+def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad, db1=None, db2=None, db2_done=False):
+    """Returns dx (+ residual_grad), dW1, db1, dW2, db2 (db1 / db2: zeroed accumulators, optional;
+    db2_done: db2 already holds the column sums of dy -- the LayerNorm backward that made dy summed them)."""
     _, bwd_code = _act_codes(act)
-    db2 = ops.colsum(dy, out=db2)
+    if not db2_done:
+        db2 = ops.colsum(dy, out=db2)
     dw2 = _dw(dy, hmid)
     dpre = _dx(dy, w2, act=bwd_code, aux_in=pre if act == 'gelu' else hmid)
     db1 = ops.colsum(dpre, out=db1)
@@ -343,14 +345,13 @@ class DisLayerFn(torch.autograd.Function):
         F = wi.shape[0]
         R = band.shape[0] if band is not None else 0
         zp = _ZeroPool(x_ext.device, D, D, D, D, D, F, D, 3 * D, R * 2 * D)
-        dg2, dbe2 = zp.take(D), zp.take(D)
-        ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2)
+        dg2, dbe2, dbout = zp.take(D), zp.take(D), zp.take(D)
+        ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2, dxsum=dbout)
         da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, shadow(wi, dt), shadow(wout, dt), act, hmid, pre, ds2,
-                                              db1=zp.take(F), db2=zp.take(D))
-        dg1, dbe1 = zp.take(D), zp.take(D)
+                                              db1=zp.take(F), db2=dbout, db2_done=True)
+        dg1, dbe1, dbo = zp.take(D), zp.take(D), zp.take(D)
         ds1_ext = torch.empty(ME, D, device=x_ext.device, dtype=dt)
-        ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1])
-        dbo = ops.colsum(ds1, out=zp.take(D))
+        ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
         dwo = _dw(ds1, attn)
         dattn = _dx(ds1, shadow(wo, dt))
         dqkv_ext = torch.empty(ME, 3 * D, device=x_ext.device, dtype=dt)

@@ -125,9 +125,10 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats=True, out=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, add=None, out=None):
-    """Returns dx (+ add).  dgamma / dbeta (fp32 [D]) are accumulated into."""
-    _req_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, add, out)
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, add=None, out=None, dxsum=None):
+    """Returns dx (+ add).  dgamma / dbeta (fp32 [D]) are accumulated into, as is dxsum (fp32 [D],
+    column sums of the returned dx) when given."""
+    _req_cuda(dy, x, mean, rstd, gamma, dgamma, dbeta, add, out, dxsum)
     pdy, rows, D, lddy = _rows2d(dy, 'layernorm dy')
     px, _, _, ldx = _rows2d(x, 'layernorm x')
     dx = out if out is not None else torch.empty(rows, D, device=x.device, dtype=x.dtype)
@@ -142,7 +143,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, add=None, out=None):
         raise ValueError('layernorm_bwd: x / dy mismatch')
     st = lib().vitk_layernorm_bwd(_dt(x), rows, D, pdy, lddy, px, ldx, mean.data_ptr(), rstd.data_ptr(),
                                   gamma.data_ptr(), padd, ldadd, dx.data_ptr(), D, _ptr(dgamma), _ptr(dbeta),
-                                  _stream())
+                                  _ptr(dxsum), _stream())
     check(st, 'vitk_layernorm_bwd')
     return dx
 
