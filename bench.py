@@ -149,7 +149,8 @@ def main():
     torch.manual_seed(0)       # identical init on every rank (rank 0 is broadcast anyway)
     net = build_model(variant, preset, img_size=img, patch_size=patch, num_classes=classes,
                       mask_epochs=MASK_EPOCHS if 'lai' in variant else None, dtype=dtype, device=dev)
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, fused=True)
+    from vit_amd.optim import AdamW
+    opt = AdamW(net.parameters(), lr=1e-4)
     reducer = None
     if world > 1 or args.force_reducer:
         from vit_amd.ddp import GradReducer

@@ -74,6 +74,17 @@ int vitk_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, vo
 /* direction 0: fp32 -> bf16, 1: bf16 -> fp32, n elements (weight shadows for the bf16 path). */
 int vitk_cast(int direction, long n, const void* src, void* dst, void* stream);
 
+/* One torch.optim.AdamW step (the optimizer train.py:275 builds and :549 steps; torch defaults
+ * betas 0.9/0.999, eps 1e-8, weight_decay 1e-2) over one fp32 parameter viewed as [rows, cols]
+ * (cols % 4 == 0), `step` counting from 1:
+ *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * and, in the same pass, the bf16 copies of the new p that the GEMMs read: shadow [rows][ld_shadow]
+ * (may be NULL) and shadow_t [cols][ld_shadow_t] = the transpose (may be NULL).  SURVEY 8(f)-2. */
+int vitk_adamw(int rows, int cols, float* p, const float* g, float* m, float* v, double lr, double beta1,
+               double beta2, double eps, double weight_decay, int step, void* shadow, long ld_shadow,
+               void* shadow_t, long ld_shadow_t, void* stream);
+
 /* Patch gather / scatter for Conv2d(kernel = stride = P): out[(b*nph+ph)*npw+pw][(c*P+py)*P+px] =
  * img[b][c][ph*P+py][pw*P+px]  (model.py:92-99: proj(x).flatten(2).transpose(1,2)). */
 int vitk_patchify(int img_dtype, int out_dtype, int B, int C, int H, int W, int P, const void* img,

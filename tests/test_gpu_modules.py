@@ -146,7 +146,8 @@ def test_config1_step_vs_reference_golden(dtype):
     prec.set_compute_dtype(net.cuda(), dtype)
     img = gi.randn(51, 'img', 8, 3, 32, 32).cuda()
     tgt = torch.from_numpy(g['target']).cuda()
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    from vit_amd import optim as vitk_optim
+    opt = vitk_optim.AdamW(net.parameters(), lr=1e-4)      # train.py:275, through vitk_adamw
     logits = net(img)
     tol = TOL[dtype] * (3 if dtype == torch.float32 else 1)
     assert relerr(logits.detach().cpu(), g['logits']) < tol

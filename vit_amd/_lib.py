@@ -13,7 +13,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
 
 _lib = None
 
-c_int, c_long, c_float, c_vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+c_int, c_long, c_float, c_double, c_vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 _SIGNATURES = {
     'vitk_version': ([], c_int),
@@ -28,6 +28,8 @@ _SIGNATURES = {
                             c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp, c_vp], c_int),
     'vitk_colsum': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_vp], c_int),
     'vitk_cast': ([c_int, c_long, c_vp, c_vp, c_vp], c_int),
+    'vitk_adamw': ([c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_double, c_double, c_double, c_int,
+                    c_vp, c_long, c_vp, c_long, c_vp], c_int),
     'vitk_patchify': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp], c_int),
     'vitk_unpatchify': ([c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp], c_int),
     'vitk_cls_rows': ([c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp], c_int),

@@ -1,0 +1,129 @@
+// AdamW step of one [rows, cols] fp32 parameter, fused with the refresh of its compute-dtype copies.
+//
+// Reference: torch.optim.AdamW(model.parameters(), lr=1e-4) built at train.py:275 and stepped at
+// train.py:549 (torch defaults: betas 0.9 / 0.999, eps 1e-8, weight_decay 1e-2, no amsgrad):
+//     p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2
+//     p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// HBM-bound: 16 B read + 12 B written per element, plus 2 + 2 B for the two bf16 copies the GEMMs
+// read: `shadow` (same [out, in] layout: forward and dW) and `shadow_t` (transposed, [in, out]: the
+// dX GEMMs then read both operands K-contiguous).  A 64 x 64 tile per workgroup; the transposed copy
+// goes through LDS so that both copies are written in 8/16-byte pieces.
+#include "common.h"
+
+namespace vitk {
+
+constexpr int OPT_TILE = 64;
+constexpr int OPT_LD = OPT_TILE + 8;   // LDS row stride (bf16): 144 B keeps 16-byte alignment, spreads banks
+
+struct AdamWParams {
+    float* p;
+    const float* g;
+    float *m, *v;
+    __bf16* shadow;
+    long ld_shadow;
+    __bf16* shadow_t;
+    long ld_shadow_t;
+    int rows, cols;
+    float decay;        // 1 - lr * wd
+    float b1, b2;
+    float omb1, omb2;   // 1 - b1, 1 - b2, rounded from double as torch does
+    float step_size;    // lr / (1 - b1^t)
+    float inv_bc2_sqrt; // 1 / sqrt(1 - b2^t)
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[OPT_TILE * OPT_LD];   // [col][row]
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.y * OPT_TILE, c0 = blockIdx.x * OPT_TILE;
+    const int cg = t & 15, rr = t >> 4;
+    const int c = c0 + 4 * cg;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int rl = rr + 16 * pass;
+        const int r = r0 + rl;
+        f32x4 pn = {0.f, 0.f, 0.f, 0.f};
+        if (r < a.rows && c < a.cols) {      // cols % 4 == 0 (host-checked): the whole vector is in range
+            const long off = (long)r * a.cols + c;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + off);
+            f32x4 p = *reinterpret_cast<const f32x4*>(a.p + off);
+            f32x4 m = *reinterpret_cast<const f32x4*>(a.m + off);
+            f32x4 v = *reinterpret_cast<const f32x4*>(a.v + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p[e] *= a.decay;
+                m[e] += a.omb1 * (g[e] - m[e]);                       // torch: exp_avg.lerp_(grad, 1 - beta1)
+                v[e] = a.b2 * v[e] + a.omb2 * g[e] * g[e];
+                const float denom = sqrtf(v[e]) * a.inv_bc2_sqrt + a.eps;
+                p[e] -= a.step_size * (m[e] / denom);
+            }
+            *reinterpret_cast<f32x4*>(a.p + off) = p;
+            *reinterpret_cast<f32x4*>(a.m + off) = m;
+            *reinterpret_cast<f32x4*>(a.v + off) = v;
+            pn = p;
+            if (a.shadow)
+                *reinterpret_cast<bf16x4*>(a.shadow + (long)r * a.ld_shadow + c) =
+                    bf16x4{(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+        }
+        if (a.shadow_t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(4 * cg + e) * OPT_LD + rl] = (__bf16)pn[e];
+        }
+    }
+    if (!a.shadow_t) return;
+    __syncthreads();
+    // transposed copy: row (c0 + cl) of shadow_t gets rows r0 .. r0+63 of this tile
+    const int rg = t & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int cl = (t >> 3) + 32 * pass;
+        const int cc = c0 + cl, r = r0 + 8 * rg;
+        if (cc >= a.cols || r >= a.rows) continue;
+        __bf16* dst = a.shadow_t + (long)cc * a.ld_shadow_t + r;
+        const __bf16* src = tile + cl * OPT_LD + 8 * rg;
+        if (r + 8 <= a.rows && (a.ld_shadow_t & 7) == 0) {
+            *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
+        } else {
+            for (int e = 0; e < 8 && r + e < a.rows; ++e) dst[e] = src[e];
+        }
+    }
+}
+
+}  // namespace vitk
+
+using namespace vitk;
+
+extern "C" int vitk_adamw(int rows, int cols, float* p, const float* g, float* m, float* v, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, int step, void* shadow, long ld_shadow,
+                          void* shadow_t, long ld_shadow_t, hipStream_t stream) {
+    VITK_CHECK_ARG(rows >= 0 && cols >= 0 && cols % 4 == 0, "vitk_adamw: cols=%d must be a multiple of 4", cols);
+    VITK_CHECK_ARG(step >= 1, "vitk_adamw: step counts from 1");
+    if (rows == 0 || cols == 0) return VITK_OK;
+    VITK_CHECK_ARG(p && g && m && v, "vitk_adamw: null tensor");
+    auto al = [](const void* q, int a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+    VITK_CHECK_ARG(al(p, 16) && al(g, 16) && al(m, 16) && al(v, 16), "vitk_adamw: tensors must be 16-byte aligned");
+    VITK_CHECK_ARG(!shadow || (ld_shadow >= cols && ld_shadow % 4 == 0 && al(shadow, 8)),
+                   "vitk_adamw: shadow needs ld >= cols, ld %% 4 == 0 and 8-byte alignment");
+    VITK_CHECK_ARG(!shadow_t || (ld_shadow_t >= rows && al(shadow_t, 16)),
+                   "vitk_adamw: shadow_t needs ld >= rows and 16-byte alignment");
+    AdamWParams a;
+    a.p = p; a.g = g; a.m = m; a.v = v;
+    a.shadow = (__bf16*)shadow; a.ld_shadow = ld_shadow;
+    a.shadow_t = (__bf16*)shadow_t; a.ld_shadow_t = ld_shadow_t;
+    a.rows = rows; a.cols = cols;
+    // hyper-parameters arrive as doubles (Python floats) and are rounded once, as torch rounds them
+    a.decay = (float)(1.0 - lr * weight_decay);
+    a.b1 = (float)beta1; a.b2 = (float)beta2;
+    a.omb1 = (float)(1.0 - beta1);
+    a.omb2 = (float)(1.0 - beta2);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    a.step_size = (float)(lr / bc1);
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    a.eps = (float)eps;
+    const dim3 grid((cols + OPT_TILE - 1) / OPT_TILE, (rows + OPT_TILE - 1) / OPT_TILE);
+    VITK_CHECK_ARG(grid.y <= 65535, "vitk_adamw: too many rows");
+    hipLaunchKernelGGL(adamw_kernel, grid, dim3(256), 0, stream, a);
+    VITK_CHECK_LAUNCH("vitk_adamw");
+    return VITK_OK;
+}

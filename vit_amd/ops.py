@@ -148,6 +148,39 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, add=None, out=None, d
     return dx
 
 
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, shadow=None, shadow_t=None):
+    """In-place torch.optim.AdamW step of one fp32 parameter (>= 2-D, viewed as [shape[0], -1]); also
+    rewrites its bf16 copies: ``shadow`` = (tensor, row offset) in the [out, in] layout, ``shadow_t`` =
+    (tensor, column offset) in the transposed layout (both optional)."""
+    _req_cuda(p, g, m, v)
+    rows = p.shape[0]
+    cols = p.numel() // rows if rows else 0
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != p.shape:
+            raise ValueError('adamw_step: p, g, m, v must be contiguous fp32 tensors of one shape')
+    ps = pt = 0
+    lds = ldt = 0
+    if shadow is not None:
+        buf, off = shadow
+        _req_cuda(buf)
+        if buf.dtype != torch.bfloat16 or buf.dim() != 2 or buf.stride(1) != 1 or buf.shape[1] != cols \
+                or off < 0 or off + rows > buf.shape[0]:
+            raise ValueError('adamw_step: shadow must be a bf16 [>= off + rows, cols] matrix')
+        lds = buf.stride(0)
+        ps = buf.data_ptr() + off * lds * 2
+    if shadow_t is not None:
+        buf, off = shadow_t
+        _req_cuda(buf)
+        if buf.dtype != torch.bfloat16 or buf.dim() != 2 or buf.stride(1) != 1 or buf.shape[0] != cols \
+                or off < 0 or off + rows > buf.shape[1]:
+            raise ValueError('adamw_step: shadow_t must be a bf16 [cols, >= off + rows] matrix')
+        ldt = buf.stride(0)
+        pt = buf.data_ptr() + off * 2
+    st = lib().vitk_adamw(rows, cols, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), float(lr), float(beta1),
+                          float(beta2), float(eps), float(weight_decay), int(step), ps, lds, pt, ldt, _stream())
+    check(st, 'vitk_adamw')
+
+
 def colsum(x, out=None):
     """out[n] += sum_m x[m][n] (fp32).  A fresh zeroed ``out`` is made when none is given."""
     _req_cuda(x, out)

@@ -1,0 +1,94 @@
+"""AdamW over the HIP library: the optimizer either side of the hot path.
+
+Reference: ``optimizer = optim.AdamW(model.parameters(), lr=args.lr)`` (train.py:275), stepped once per
+batch (train.py:549) -- torch.optim.AdamW with torch's defaults (betas 0.9 / 0.999, eps 1e-8,
+weight_decay 1e-2, no amsgrad).  Same constructor surface, same ``param_groups`` (so
+``StepLR`` of train.py:276 drives ``lr``), same update rule, same state names (``exp_avg``,
+``exp_avg_sq``, ``step``).
+
+Every parameter with >= 2 dims (99.9 % of the bytes) goes through ``vitk_adamw``: one pass that also
+rewrites the bf16 copies of the new value the GEMMs read -- the [out, in] copy (forward, dW) and the
+transposed copy (dX) -- so no cast / transpose kernel runs in steady state (functional.shadow).
+The 1-D rest (biases, LayerNorm weights) takes torch's fused multi-tensor kernel (plumbing).
+There is no CPU path: the HIP library must be present.
+"""
+import importlib
+
+import torch
+
+from . import ops
+from . import functional as VF
+
+
+_torch_adamw = importlib.import_module('torch.optim.adamw').adamw     # functional multi-tensor AdamW
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *,
+                 maximize=False):
+        if amsgrad or maximize:
+            raise ValueError('vit_amd.optim.AdamW: amsgrad / maximize are not implemented (the reference uses neither)')
+        if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
+            raise ValueError('vit_amd.optim.AdamW: invalid hyper-parameter')
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @staticmethod
+    def _native(p):
+        """Parameters the HIP kernel updates: fp32, on the GPU, >= 2-D, rows of whole 16-byte vectors."""
+        return (p.is_cuda and p.dtype == torch.float32 and p.dim() >= 2 and p.is_contiguous()
+                and p.shape[0] > 0 and (p.numel() // p.shape[0]) % 4 == 0 and p.data_ptr() % 16 == 0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+            small, small_g, small_m, small_v, small_t = [], [], [], [], []
+            for p in group['params']:
+                g = p.grad
+                if g is None:
+                    continue
+                if g.is_sparse:
+                    raise RuntimeError('vit_amd.optim.AdamW does not support sparse gradients')
+                st = self.state[p]
+                native = self._native(p)
+                if not st:
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['step'] = torch.zeros((), dtype=torch.float32) if native else \
+                        torch.zeros((), dtype=torch.float32, device=p.device)
+                if not native:
+                    small.append(p)
+                    small_g.append(g)
+                    small_m.append(st['exp_avg'])
+                    small_v.append(st['exp_avg_sq'])
+                    small_t.append(st['step'])
+                    continue
+                st['step'] += 1
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16:
+                    g = g.float().contiguous().clone()
+                rows = p.shape[0]
+                tgt_n = tgt_t = None
+                for key, buf, off, transposed in VF.shadow_targets(p):
+                    ok = buf.dtype == torch.bfloat16 and buf.dim() == 2 and buf.is_contiguous()
+                    if ok and not transposed and tgt_n is None and buf.shape[1] * rows == p.numel() \
+                            and buf.shape[1] % 4 == 0:
+                        tgt_n = (buf, off)
+                    elif ok and transposed and tgt_t is None and buf.shape[0] * rows == p.numel() \
+                            and off % 8 == 0 and buf.data_ptr() % 16 == 0:
+                        tgt_t = (buf, off)
+                    else:
+                        VF.shadow_drop(key)      # cannot be rewritten here: rebuilt from p at its next use
+                ops.adamw_step(p, g, st['exp_avg'], st['exp_avg_sq'], lr, b1, b2, eps, wd, int(st['step'].item()),
+                               shadow=tgt_n, shadow_t=tgt_t)
+            if small:
+                if small[0].is_cuda:
+                    _torch_adamw(small, small_g, small_m, small_v, [], small_t, amsgrad=False, beta1=b1,
+                                            beta2=b2, lr=lr, weight_decay=wd, eps=eps, maximize=False, fused=True,
+                                            grad_scale=None, found_inf=None)
+                else:
+                    raise RuntimeError('vit_amd.optim.AdamW: parameters must live on the GPU (no CPU path)')
+        return loss
