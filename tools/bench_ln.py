@@ -27,3 +27,6 @@ t = bench(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, add=add)); pri
 big = torch.randn(M, 4096, device='cuda').bfloat16()
 t = bench(lambda: ops.colsum(big)); print(f'colsum 4096 {t:7.1f} us  ({4*mb/t:.2f} TB/s)')
 t = bench(lambda: ops.colsum(x)); print(f'colsum 1024 {t:7.1f} us  ({mb/t:.2f} TB/s)')
+t = bench(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, None, None, add=add)); print(f'ln bwd+add without the dgamma/dbeta flush {t:7.1f} us')
+dxs = torch.zeros(D, device='cuda')
+t = bench(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, add=add, dxsum=dxs)); print(f'ln bwd+add+dxsum {t:7.1f} us')

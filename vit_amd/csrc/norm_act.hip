@@ -30,6 +30,30 @@ template <> __device__ __forceinline__ void load8<__bf16>(float (&v)[8], const _
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
 }
+// 8 elements as loaded (packed): lets a kernel keep the NEXT row's loads in flight in few registers
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4*>(p);
+        b = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = a[e];
+            v[4 + e] = b[e];
+        }
+    }
+};
+template <> struct Raw8<__bf16> {
+    bf16x8 a;
+    __device__ __forceinline__ void load(const __bf16* p) { a = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    }
+};
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
@@ -119,12 +143,10 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
                                                             float* __restrict__ dbeta,
                                                             float* __restrict__ dxsum, int rows, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw);  // [3][D]
+    float* red = reinterpret_cast<float*>(smem_raw);  // [LN_BWD_WAVES][D]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunk = D >> 3;
-    for (int i = threadIdx.x; i < 3 * D; i += LN_BWD_THREADS) red[i] = 0.f;
-    __syncthreads();
     float dg[NV][8], db[NV][8], g[NV][8], ds[NV][8];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -138,16 +160,41 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
         }
         if (c < nchunk) load8<float>(g[i], gamma + c * 8);
     }
-    for (long row = (long)blockIdx.x * LN_BWD_WAVES + wave; row < rows; row += (long)gridDim.x * LN_BWD_WAVES) {
-        const float mu = mean[row], rs = rstd[row];
-        float vdy[NV][8], xh[NV][8];
+    // The row loop is latency-bound (two waves per SIMD): the next row's dy / x / add loads are issued
+    // before this row's reductions, kept packed (12 registers per chunk for bf16).
+    const long stride = (long)gridDim.x * LN_BWD_WAVES;
+    long row = (long)blockIdx.x * LN_BWD_WAVES + wave;
+    Raw8<T> ndy[NV], nx[NV], nadd[NV];
+    float nmu = 0.f, nrs = 0.f;
+    auto fetch = [&](long r) {
+        nmu = mean[r];
+        nrs = rstd[r];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                ndy[i].load(dy + r * lddy + c * 8);
+                nx[i].load(x + r * ldx + c * 8);
+                if (add) nadd[i].load(add + r * ldadd + c * 8);
+            }
+        }
+    };
+    if (row < rows) fetch(row);
+    for (; row < rows; row += stride) {
+        const float mu = nmu, rs = nrs;
+        float vdy[NV][8], xh[NV][8], va[NV][8];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            ndy[i].unpack(vdy[i]);
+            nx[i].unpack(xh[i]);
+            if (add) nadd[i].unpack(va[i]);
+        }
+        if (row + stride < rows) fetch(row + stride);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                load8<T>(vdy[i], dy + row * lddy + c * 8);
-                load8<T>(xh[i], x + row * ldx + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     xh[i][e] = (xh[i][e] - mu) * rs;
@@ -169,10 +216,8 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] * vdy[i][e] - s1 - xh[i][e] * s2);
                 if (add) {
-                    float a[8];
-                    load8<T>(a, add + row * ldadd + c * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += a[e];
+                    for (int e = 0; e < 8; ++e) o[e] += va[i][e];
                 }
                 if (dxsum) {
 #pragma unroll
@@ -182,29 +227,35 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void layernorm_bwd_kernel(const T* 
             }
         }
     }
+    // Block reduction without LDS atomics (lane-strided LDS atomics are 8-way bank conflicts: ~10 us
+    // per array): every wave parks its partial row in LDS, the block sums the 8 rows per column and
+    // issues one global atomic per column.  Every block finishes at about the same time: each
+    // block starts at a rotated column so that concurrent blocks add to different addresses.
+    const int rot = (blockIdx.x * 256) % D;
+    auto flush = [&](const float (&part)[NV][8], float* __restrict__ out) {
+        __syncthreads();                       // the previous array's column sums are done with `red`
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                atomicAdd(&red[c * 8 + e], dg[i][e]);
-                atomicAdd(&red[D + c * 8 + e], db[i][e]);
-                if (dxsum) atomicAdd(&red[2 * D + c * 8 + e], ds[i][e]);
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float* dst = red + wave * D + c * 8;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{part[i][0], part[i][1], part[i][2], part[i][3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{part[i][4], part[i][5], part[i][6], part[i][7]};
             }
         }
-    }
-    __syncthreads();
-    // every block finishes at about the same time: rotate each block's starting column so that
-    // concurrent blocks add to different addresses (same-address atomics serialise in the L2)
-    const int rot = (blockIdx.x * 256) % D;
-    for (int i = threadIdx.x; i < D; i += LN_BWD_THREADS) {
-        int c = i + rot;
-        if (c >= D) c -= D;
-        if (dgamma) atomicAdd(&dgamma[c], red[c]);
-        if (dbeta) atomicAdd(&dbeta[c], red[D + c]);
-        if (dxsum) atomicAdd(&dxsum[c], red[2 * D + c]);
-    }
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += LN_BWD_THREADS) {
+            int c = i + rot;
+            if (c >= D) c -= D;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < LN_BWD_WAVES; ++w) sum += red[w * D + c];
+            atomicAdd(&out[c], sum);
+        }
+    };
+    if (dgamma) flush(dg, dgamma);
+    if (dbeta) flush(db, dbeta);
+    if (dxsum) flush(ds, dxsum);
 }
 
 // ------------------------------------------------------------------ column sums
@@ -400,7 +451,7 @@ static void ln_bwd_dispatch(int rows, int D, const T* dy, long lddy, const T* x,
         cus = n;
     }
     if (grid > cus) grid = cus;
-    const size_t lds = 3 * (size_t)D * sizeof(float);
+    const size_t lds = (size_t)LN_BWD_WAVES * D * sizeof(float);
 #define L(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(LN_BWD_THREADS), lds, st, dy, lddy, x, ldx, mean, rstd, gamma, add, ldadd, dx, lddx, dgamma, dbeta, dxsum, rows, D)
     if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 3) L(3); else L(4);
 #undef L

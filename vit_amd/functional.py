@@ -318,9 +318,8 @@ class PreLNBlockFn(torch.autograd.Function):
         zp = _ZeroPool(x.device, D, D, D, D, D, F, D, 3 * D)
         dh2, dw1, db1, dw2, db2 = _mlp_bwd(dy, h2, w1, w2, act, hmid, pre, None,
                                            db1=zp.take(F), db2=zp.take(D))
-        dg2, dbe2 = zp.take(D), zp.take(D)
-        dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy)
-        dbproj = ops.colsum(dx1, out=zp.take(D))
+        dg2, dbe2, dbproj = zp.take(D), zp.take(D), zp.take(D)
+        dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy, dxsum=dbproj)
         dwproj = _dw(dx1, attn)
         dattn = _dx(dx1, wproj)
         dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse)
