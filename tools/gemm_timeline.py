@@ -8,23 +8,25 @@ from vit_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_stamps', 'libvitk.so')   # see header
 from vit_amd import ops
 M = 128 * 197
-for (name, m, n, k, tb) in [('qkv NT', M, 3072, 1024, True), ('proj NT', M, 1024, 1024, True), ('fc2 NT', M, 1024, 4096, True),
-                            ('dx fc2 NN', M, 4096, 1024, False), ('sq4096 NT', 4096, 4096, 4096, True)]:
-    a = torch.randn(m, k, device='cuda').bfloat16()
+MP = M + 448
+for (name, m, n, k, ta, tb) in [('qkv NT', M, 3072, 1024, False, True), ('fc2 NT', M, 1024, 4096, False, True),
+                                ('dw fc1 TN', 4096, 1024, MP, True, False), ('dw proj TN', 1024, 1024, MP, True, False),
+                                ('dw qkv TN', 3072, 1024, MP, True, False), ('sq4096 NT', 4096, 4096, 4096, False, True)]:
+    a = (torch.randn(k, m, device='cuda') if ta else torch.randn(m, k, device='cuda')).bfloat16()
     b = (torch.randn(n, k, device='cuda') if tb else torch.randn(k, n, device='cuda')).bfloat16()
-    out = torch.empty(m, n, device='cuda', dtype=torch.bfloat16)
+    out = torch.empty(m, n, device='cuda', dtype=torch.float32 if ta else torch.bfloat16)
     st = torch.zeros(m, n, device='cuda', dtype=torch.bfloat16)
     for _ in range(3):
-        ops.gemm(a, b, trans_b=tb, out=out, aux_out=st)
+        ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out, aux_out=st)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     st.zero_(); torch.cuda.synchronize()
-    e0.record(); ops.gemm(a, b, trans_b=tb, out=out, aux_out=st); e1.record(); torch.cuda.synchronize()
+    e0.record(); ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out, aux_out=st); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
     s = st.view(-1).view(torch.int64)[:256 * 64].view(256, 2, 32).cpu()
     t0 = s[:, :, 0].min().item()
     tend = s[:, :, 1:].max().item()
-    print(f'{name}: event {us:.1f} us, stamps span {tend - t0} ticks -> {(tend - t0) / us:.1f} ticks/us', flush=True)
+    print(f'{name}: event {us:.1f} us (cold, one call)', flush=True)
     for blk in (0, 1, 100, 255):
         row = s[blk, 0]
         items = []

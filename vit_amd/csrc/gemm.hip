@@ -278,7 +278,14 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
     p.c_vec8_ok = p.c_vec_ok && al(C, 16) && (ldc * csz) % 16 == 0 && al(aux_in, 16) && al(aux_out, 16) &&
                   al(residual, 16) && ((!aux_in && !aux_out) || ld_aux % 8 == 0) && (!residual || ldr % 8 == 0);
     p.alpha = alpha;
-    const bool linear_f32 = c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out && grp_rows == 0;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VITK_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+#ifdef VITK_GEMM_STAMPS
+    const bool stamping = (p.debug & 96) != 0;   // aux_out is the stamp buffer (tools/gemm_timeline.py), not an output
+#else
+    const bool stamping = false;
+#endif
+    const bool has_aux_out = aux_out && !stamping;
+    const bool linear_f32 = c_dtype == VITK_F32 && act == ACT_NONE && !residual && !has_aux_out && grp_rows == 0;
     // The 256-tile kernel runs one workgroup per CU: a problem with few tiles and no split-K (bf16 output,
     // e.g. the 393-row relative-table GEMMs) would leave most of the chip idle -> finer 128 x 128 tiles.
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
@@ -307,7 +314,7 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
         splitk = (ksteps + per - 1) / per;
     }
     if (splitk > 1) {
-        VITK_CHECK_ARG(c_dtype == VITK_F32 && act == ACT_NONE && !residual && !aux_out,
+        VITK_CHECK_ARG(c_dtype == VITK_F32 && act == ACT_NONE && !residual && !has_aux_out,
                        "vitk_gemm: split-K needs an fp32 output and a linear epilogue");
         if (!accumulate) {
             if (ldc == N && grp_rows == 0) {
@@ -325,7 +332,6 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
     }
     p.splitk = splitk;
     p.tiles_m = tiles_m; p.tiles_n = tiles_n;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VITK_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
     if (big) {
         gemm256_launch(p, c_dtype, transA, transB, stream);
         VITK_CHECK_LAUNCH("vitk_gemm");
