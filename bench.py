@@ -37,6 +37,7 @@ WORKLOADS = {
     'lai_s16': ('transformer_timm_lai', 'S', 224, 16, 1000, 128),
     'dislai_l16': ('disentangled_lai_attention', 'L', 224, 16, 1000, 64),
     'regular_cifar': ('transformer', 'cifar', 32, 4, 10, 128),
+    'performer_s16_384': ('performer_timm', 'S', 384, 16, 1000, 64),      # config 5, FAVOR+ m = 64 (GPU line only)
 }
 MASK_EPOCHS = [10, 20, 30, 40]
 STAGE_EPOCH = {8: 0, 12: 10, 18: 20, 20: 30, -1: 40}
@@ -52,6 +53,9 @@ def train_flops_per_image(variant, p, N, P, C, B, w):
     if variant.startswith('disentangled'):
         attn = 8.0 * N * wbar * D
         table = 4.0 * (2 * N - 1) * D * D / B
+    elif variant.startswith('performer'):
+        attn = 8.0 * N * D * 64 + 2.0 * N * 64 * H        # FAVOR+ with m = 64 random features
+        table = 0.0
     else:
         attn = 4.0 * N * wbar * D
         table = 0.0
@@ -218,7 +222,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not variant.startswith('performer'):   # no oracle model of config 5's shell
             cpu = cpu_baseline(args, variant, preset, img, patch, classes, w)
         out = {
             'metric': 'train images/sec (node) ViT-B/16-224 LAI+Dis' if args.workload == 'dislai_b16'

@@ -18,6 +18,11 @@ from .ops import ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU
 
 _shadow = {}          # key -> (versions, copy, weakrefs, transposed)
 _shadow_index = {}    # id(param) -> keys of the cached copies it is part of
+_shadow_gen = [0]     # bumped whenever a copy is created or dropped (optim.AdamW caches its launch plans on it)
+
+
+def shadow_generation():
+    return _shadow_gen[0]
 
 
 def _rows_of(p):
@@ -58,11 +63,13 @@ def shadow(params, dtype, transposed=False):
     if len(_shadow) > 4096:
         for k in [k for k, v in _shadow.items() if any(r() is None for r in v[2])]:
             del _shadow[k]
+        _shadow_gen[0] += 1
         for pid in list(_shadow_index):
             _shadow_index[pid] = [k for k in _shadow_index[pid] if k in _shadow]
             if not _shadow_index[pid]:
                 del _shadow_index[pid]
     _shadow[key] = (ver, dst, tuple(weakref.ref(p) for p in params), transposed)
+    _shadow_gen[0] += 1
     for p in params:
         keys = _shadow_index.setdefault(id(p), [])
         if key not in keys:
@@ -94,7 +101,8 @@ def shadow_targets(p):
 
 
 def shadow_drop(key):
-    _shadow.pop(key, None)
+    if _shadow.pop(key, None) is not None:
+        _shadow_gen[0] += 1
 
 
 def _f32(t):

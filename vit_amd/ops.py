@@ -22,7 +22,14 @@ def _dt(t):
     raise TypeError(f'vit_amd supports float32 / bfloat16 tensors, got {t.dtype}')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream (the raw getter is ~20x cheaper than building a Stream object:
+    it is called once per kernel launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -16,8 +16,9 @@ import importlib
 
 import torch
 
-from . import ops
 from . import functional as VF
+from ._lib import lib, check
+from .ops import _stream
 
 
 _torch_adamw = importlib.import_module('torch.optim.adamw').adamw     # functional multi-tensor AdamW
@@ -38,29 +39,59 @@ class AdamW(torch.optim.Optimizer):
         return (p.is_cuda and p.dtype == torch.float32 and p.dim() >= 2 and p.is_contiguous()
                 and p.shape[0] > 0 and (p.numel() // p.shape[0]) % 4 == 0 and p.data_ptr() % 16 == 0)
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.get('_plans', {}).clear()      # the moment buffers were replaced
+
+    def _plan(self, p, st):
+        """Launch arguments of one native parameter that do not change from step to step (everything
+        but the gradient pointer): valid while functional's set of cached copies is unchanged."""
+        rows = p.shape[0]
+        cols = p.numel() // rows
+        ps = lds = pt = ldt = 0
+        for key, buf, off, transposed in VF.shadow_targets(p):
+            ok = buf.dtype == torch.bfloat16 and buf.is_contiguous() and buf.numel() > 0
+            if ok and not transposed and not ps and buf.numel() // buf.shape[0] == cols and cols % 4 == 0 \
+                    and off + rows <= buf.shape[0]:
+                lds = cols
+                ps = buf.data_ptr() + off * lds * 2
+            elif ok and transposed and not pt and buf.dim() == 2 and buf.shape[0] == cols and off % 8 == 0 \
+                    and buf.data_ptr() % 16 == 0 and off + rows <= buf.shape[1]:
+                ldt = buf.stride(0)
+                pt = buf.data_ptr() + off * 2
+            else:
+                VF.shadow_drop(key)      # cannot be rewritten here: rebuilt from p at its next use
+        return (rows, cols, p.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), ps, lds, pt, ldt)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        L = lib()
+        stream = None
+        plans = self.__dict__.setdefault('_plans', {})
+        if self.__dict__.get('_plan_gen') != VF.shadow_generation():
+            plans.clear()
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+            lr, b1, b2, eps, wd = float(lr), float(b1), float(b2), float(eps), float(wd)
             small, small_g, small_m, small_v, small_t = [], [], [], [], []
             for p in group['params']:
                 g = p.grad
                 if g is None:
                     continue
-                if g.is_sparse:
-                    raise RuntimeError('vit_amd.optim.AdamW does not support sparse gradients')
                 st = self.state[p]
-                native = self._native(p)
                 if not st:
+                    if g.is_sparse:
+                        raise RuntimeError('vit_amd.optim.AdamW does not support sparse gradients')
+                    st['native'] = self._native(p)
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st['step'] = torch.zeros((), dtype=torch.float32) if native else \
+                    st['step'] = torch.zeros((), dtype=torch.float32) if st['native'] else \
                         torch.zeros((), dtype=torch.float32, device=p.device)
-                if not native:
+                if not st['native']:
                     small.append(p)
                     small_g.append(g)
                     small_m.append(st['exp_avg'])
@@ -68,27 +99,22 @@ class AdamW(torch.optim.Optimizer):
                     small_t.append(st['step'])
                     continue
                 st['step'] += 1
-                if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16:
-                    g = g.float().contiguous().clone()
-                rows = p.shape[0]
-                tgt_n = tgt_t = None
-                for key, buf, off, transposed in VF.shadow_targets(p):
-                    ok = buf.dtype == torch.bfloat16 and buf.dim() == 2 and buf.is_contiguous()
-                    if ok and not transposed and tgt_n is None and buf.shape[1] * rows == p.numel() \
-                            and buf.shape[1] % 4 == 0:
-                        tgt_n = (buf, off)
-                    elif ok and transposed and tgt_t is None and buf.shape[0] * rows == p.numel() \
-                            and off % 8 == 0 and buf.data_ptr() % 16 == 0:
-                        tgt_t = (buf, off)
-                    else:
-                        VF.shadow_drop(key)      # cannot be rewritten here: rebuilt from p at its next use
-                ops.adamw_step(p, g, st['exp_avg'], st['exp_avg_sq'], lr, b1, b2, eps, wd, int(st['step'].item()),
-                               shadow=tgt_n, shadow_t=tgt_t)
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16 or g.shape != p.shape:
+                    g = g.float().contiguous().clone().view_as(p)
+                plan = plans.get(id(p))
+                if plan is None or plan[2] != p.data_ptr():
+                    plan = plans[id(p)] = self._plan(p, st)
+                if stream is None:
+                    stream = _stream()
+                rows, cols, pp, pm, pv, ps, lds, pt, ldt = plan
+                check(L.vitk_adamw(rows, cols, pp, g.data_ptr(), pm, pv, lr, b1, b2, eps, wd, int(st['step']),
+                                   ps, lds, pt, ldt, stream), 'vitk_adamw')
             if small:
                 if small[0].is_cuda:
                     _torch_adamw(small, small_g, small_m, small_v, [], small_t, amsgrad=False, beta1=b1,
-                                            beta2=b2, lr=lr, weight_decay=wd, eps=eps, maximize=False, fused=True,
-                                            grad_scale=None, found_inf=None)
+                                 beta2=b2, lr=lr, weight_decay=wd, eps=eps, maximize=False, fused=True,
+                                 grad_scale=None, found_inf=None)
                 else:
                     raise RuntimeError('vit_amd.optim.AdamW: parameters must live on the GPU (no CPU path)')
+        self._plan_gen = VF.shadow_generation()
         return loss
