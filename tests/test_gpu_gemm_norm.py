@@ -226,7 +226,7 @@ def test_gemm256_epilogues():
 
 
 @pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False)])
-@pytest.mark.parametrize('M,N,K', [(4360, 4096, 192), (25216, 1024, 128)])
+@pytest.mark.parametrize('M,N,K', [(4360, 4096, 192), (25216, 1024, 128), (25664, 3072, 128), (25664 + 16, 1024, 192)])
 def test_gemm256_persistent_items(ta, tb, M, N, K):
     """More tiles than CUs: a workgroup of the persistent kernel walks several work items and the
     K-tile pipeline crosses item boundaries (ragged last row of tiles included)."""
@@ -250,3 +250,8 @@ def test_gemm256_persistent_items(ta, tb, M, N, K):
         assert relerr(y, torch.nn.functional.gelu(ref + bias)) < 1.5e-2
         # every element, not only the max-norm: a misplaced tile would pass a max-norm check on noise-like data
         assert (y.float() - torch.nn.functional.gelu(ref + bias)).abs().max().item() < 0.25
+        # side-operand epilogue (the hand-counted loads): relu gate on a saved activation + plain store
+        gate = torch.randn(M, N, device='cuda').bfloat16()
+        y = ops.gemm(a, b, trans_b=tb, act=ops.ACT_DRELU, aux_in=gate)
+        want = torch.where(gate.float() > 0, ref, torch.zeros_like(ref))
+        assert (y.float() - want).abs().max().item() < 0.25 and relerr(y, want) < 1.5e-2

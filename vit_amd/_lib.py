@@ -6,7 +6,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libvitk.so')
+LIB_PATH = os.environ.get('VITK_LIB') or os.path.join(HERE, 'lib', 'libvitk.so')   # VITK_LIB: an instrumented build (tools/)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
