@@ -339,6 +339,23 @@ class PreLNBlockFn(torch.autograd.Function):
         return dx, dg1, dbe1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbe2, dw1, db1, dw2, db2, None
 
 
+_ext_ws = {}
+
+
+def _ext_workspace(tag, rows, cols, dtype, device):
+    """Backward scratch of the extended-row layout ([tokens + table rows, cols]), one per shape for the
+    whole model: layers run one after the other on the stream, nothing here is saved or returned,
+    and the rows past the tokens that must read as zero are zeroed ONCE (kernels only write the
+    token rows; the table-gradient rows are rewritten whole every layer)."""
+    key = (tag, rows, cols, dtype, device)
+    buf = _ext_ws.get(key)
+    if buf is None:
+        if len(_ext_ws) > 16:
+            _ext_ws.clear()
+        buf = _ext_ws[key] = torch.zeros(rows, cols, device=device, dtype=dtype)
+    return buf
+
+
 def _tail_rows(M1, R):
     """Rows appended to a [M1, D] token matrix for R relative-table rows: R plus zero rows up to
     the next multiple of 64 of the total (the K dimension of the dW GEMM)."""
@@ -418,17 +435,18 @@ class DisLayerFn(torch.autograd.Function):
         da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, wi, wout, act, hmid, pre, ds2,
                                               db1=zp.take(F), db2=dbout, db2_done=True)
         dg1, dbe1, dbo = zp.take(D), zp.take(D), zp.take(D)
-        ds1_ext = torch.empty(ME, D, device=x_ext.device, dtype=dt)
+        ds1_ext = _ext_workspace('ds1', ME, D, dt, x_ext.device) if band is not None else \
+            torch.empty(ME, D, device=x_ext.device, dtype=dt)
         ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
         dwo = _dw(ds1, attn)
         dattn = _dx(ds1, wo)
-        dqkv_ext = torch.empty(ME, 3 * D, device=x_ext.device, dtype=dt)
         tables = dtab = None
         if band is not None:
+            dqkv_ext = _ext_workspace('dqkv', ME, 3 * D, dt, x_ext.device)
             tables = qkv_ext[M1:M1 + R, :2 * D]
             dtab = zp.take(R, 2 * D)
-            ds1_ext[M1:].zero_()
-            dqkv_ext[M1:].zero_()
+        else:
+            dqkv_ext = torch.empty(ME, 3 * D, device=x_ext.device, dtype=dt)
         _attn_bwd(qkv_ext[:M1], B, N, H, dh, tables, scale, w, attn, dattn, lse, dtab=dtab, dqkv=dqkv_ext[:M1])
         if band is not None:
             dqkv_ext[M1:M1 + R, :2 * D].copy_(dtab)               # (dPq | dPk) in compute dtype
