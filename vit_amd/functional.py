@@ -136,8 +136,12 @@ class _ZeroPool:
         return v
 
 
-def _dw(dy, x):
-    """dW[out, in] = dy^T x in fp32 (split-K over the token dimension)."""
+def _dw(dy, x, out=None):
+    """dW[out, in] = dy^T x in fp32 (split-K over the token dimension).  ``out``: a ZEROED fp32 buffer to
+    add into (a slice of the block's one zero-filled pool: the split-K atomics then need no memset of
+    their own -- four 6 us fills per block become part of one)."""
+    if out is not None and dy.dtype == torch.bfloat16:
+        return ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True)
     return ops.gemm(dy, x, trans_a=True, trans_b=False, out_dtype=torch.float32)
 
 
@@ -275,17 +279,17 @@ def _mlp_fwd(x, w1, b1, w2, b2, act, residual):
     return y, hmid, pre
 
 
-def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad, db1=None, db2=None, db2_done=False):
+def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad, db1=None, db2=None, db2_done=False, dw1=None, dw2=None):
     """w1 / w2: the fc1 / fc2 weight PARAMETERS (not their copies).
     Returns dx (+ residual_grad), dW1, db1, dW2, db2 (db1 / db2: zeroed accumulators, optional;
     db2_done: db2 already holds the column sums of dy -- the LayerNorm backward that made dy summed them)."""
     _, bwd_code = _act_codes(act)
     if not db2_done:
         db2 = ops.colsum(dy, out=db2)
-    dw2 = _dw(dy, hmid)
+    dw2 = _dw(dy, hmid, out=dw2)
     dpre = _dx(dy, w2, act=bwd_code, aux_in=pre if act == 'gelu' else hmid)
     db1 = ops.colsum(dpre, out=db1)
-    dw1 = _dw(dpre, x)
+    dw1 = _dw(dpre, x, out=dw1)
     dx = _dx(dpre, w1, residual=residual_grad)
     return dx, dw1, db1, dw2, db2
 
@@ -323,16 +327,16 @@ class PreLNBlockFn(torch.autograd.Function):
         dt = x.dtype
         dy = dy.contiguous()
         F = w1.shape[0]
-        zp = _ZeroPool(x.device, D, D, D, D, D, F, D, 3 * D)
+        zp = _ZeroPool(x.device, D, D, D, D, D, D, F, D, 3 * D, F * D, D * F, D * D, 3 * D * D)
         dh2, dw1, db1, dw2, db2 = _mlp_bwd(dy, h2, w1, w2, act, hmid, pre, None,
-                                           db1=zp.take(F), db2=zp.take(D))
+                                           db1=zp.take(F), db2=zp.take(D), dw1=zp.take(F, D), dw2=zp.take(D, F))
         dg2, dbe2, dbproj = zp.take(D), zp.take(D), zp.take(D)
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy, dxsum=dbproj)
-        dwproj = _dw(dx1, attn)
+        dwproj = _dw(dx1, attn, out=zp.take(D, D))
         dattn = _dx(dx1, wproj)
         dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse)
         dbqkv = ops.colsum(dqkv, out=zp.take(3 * D)) if ctx.has_qkv_bias else None
-        dwqkv = _dw(dqkv, h1)
+        dwqkv = _dw(dqkv, h1, out=zp.take(3 * D, D))
         dh1 = _dx(dqkv, wqkv)
         dg1, dbe1 = zp.take(D), zp.take(D)
         dx = ops.layernorm_bwd(dh1, x, mean1, rstd1, _f32(g1), dg1, dbe1, add=dx1)
@@ -429,16 +433,17 @@ class DisLayerFn(torch.autograd.Function):
         dy = dy.contiguous()
         F = wi.shape[0]
         R = band.shape[0] if band is not None else 0
-        zp = _ZeroPool(x_ext.device, D, D, D, D, D, F, D, 3 * D, R * 2 * D)
+        zp = _ZeroPool(x_ext.device, D, D, D, D, D, D, D, F, D, 3 * D, R * 2 * D, F * D, D * F, D * D, 3 * D * D)
         dg2, dbe2, dbout = zp.take(D), zp.take(D), zp.take(D)
         ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2, dxsum=dbout)
         da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, wi, wout, act, hmid, pre, ds2,
-                                              db1=zp.take(F), db2=dbout, db2_done=True)
+                                              db1=zp.take(F), db2=dbout, db2_done=True,
+                                              dw1=zp.take(F, D), dw2=zp.take(D, F))
         dg1, dbe1, dbo = zp.take(D), zp.take(D), zp.take(D)
         ds1_ext = _ext_workspace('ds1', ME, D, dt, x_ext.device) if band is not None else \
             torch.empty(ME, D, device=x_ext.device, dtype=dt)
         ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
-        dwo = _dw(ds1, attn)
+        dwo = _dw(ds1, attn, out=zp.take(D, D))
         dattn = _dx(ds1, wo)
         tables = dtab = None
         if band is not None:
@@ -451,7 +456,7 @@ class DisLayerFn(torch.autograd.Function):
         if band is not None:
             dqkv_ext[M1:M1 + R, :2 * D].copy_(dtab)               # (dPq | dPk) in compute dtype
         dbqkv = ops.colsum(dqkv_ext, out=zp.take(3 * D))
-        dwqkv = _dw(dqkv_ext, x_ext)
+        dwqkv = _dw(dqkv_ext, x_ext, out=zp.take(3 * D, D))
         dx_ext = _dx(dqkv_ext, (wq, wk, wv), residual=ds1_ext)
         dx = dx_ext[:M1]
         dband = dx_ext[M1:M1 + R] if band is not None else None
