@@ -408,6 +408,27 @@ __device__ __forceinline__ Item256 item256(const GemmParams& p, int item) {
         VITK_FENCE();                                                                            \
         VITK_STAMP(SI + 5);                                                                      \
     } while (0)
+// Two-phase schedule: one phase = a row half of the wave's block against all four column tiles (32 MFMAs).
+#define VITK_HALF(IT0, LGKM_FIRST)                                                               \
+    do {                                                                                         \
+        if (LGKM_FIRST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        VITK_FENCE();                                                                            \
+        __builtin_amdgcn_s_barrier();                                                            \
+        if (!(LGKM_FIRST)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+        VITK_FENCE();                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                   \
+                acc[IT0 + i_][0] = mma(fb0[0][kb], fa[i_][kb], acc[IT0 + i_][0]);                \
+                acc[IT0 + i_][1] = mma(fb0[1][kb], fa[i_][kb], acc[IT0 + i_][1]);                \
+                acc[IT0 + i_][2] = mma(fb1[0][kb], fa[i_][kb], acc[IT0 + i_][2]);                \
+                acc[IT0 + i_][3] = mma(fb1[1][kb], fa[i_][kb], acc[IT0 + i_][3]);                \
+            }                                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        VITK_FENCE();                                                                            \
+        __builtin_amdgcn_s_barrier();                                                            \
+        VITK_FENCE();                                                                            \
+    } while (0)
 #define VITK_BARRIER()                \
     do {                              \
         VITK_FENCE();                 \
@@ -429,6 +450,10 @@ __device__ __forceinline__ Item256 item256(const GemmParams& p, int item) {
 // barrier apart.  Epilogue loads / stores of an item only make the counted waits conservative.
 template <typename TC, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
+    // K-major operands (twice the LDS read instructions per fragment) run the two-phase schedule: half as
+    // many barrier hand-offs per K tile (+10 % on the dW GEMMs); K-contiguous NT measures the same either way
+    // and keeps the four-phase one.
+    constexpr bool TWO_PHASE = A_KM || B_KM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -456,8 +481,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     auto issue_slot = [&](int slot) {   // slot 0..3 of the cursor tile (slot is a literal at every call)
         if (!pf_live) return;
         char* img = smem + pf_buf * STAGE256;
-        const bool is_b = A_KM ? slot < 2 : (slot == 1 || slot == 2);
-        const int q = A_KM ? (slot & 1) : (slot == 0 || slot == 1 ? 0 : 1);
+        // two-phase schedule and K-major A: [B 0, B 1, A 0, A 1]; four-phase NT: [A q0, B 0, B 1, A q1]
+        const bool is_b = (TWO_PHASE || A_KM) ? slot < 2 : (slot == 1 || slot == 2);
+        const int q = (TWO_PHASE || A_KM) ? (slot & 1) : (slot == 0 || slot == 1 ? 0 : 1);
         if (is_b) stage_piece<B_KM, true>(B, offb, pf_ks * b_kstep, img + OPER_BYTES, q, wave);
         else stage_piece<A_KM, false>(A, offa, pf_ks * a_kstep, img, q, wave);
     };
@@ -490,8 +516,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     advance();
     issue_slot(0);
     issue_slot(1);
-    if (pf_live) VITK_VMCNT(4);
-    else VITK_VMCNT(0);
+    // in flight behind what the first phase reads.  Two-phase: B and A q0 (the whole A when it is K-major) of
+    // tile 0 -> [A q1 (2)] + B of tile 1 (4) may fly; four-phase: the two pieces of tile 1.
+    if (!pf_live) VITK_VMCNT(0);
+    else if (TWO_PHASE && !A_KM) VITK_VMCNT(6);
+    else VITK_VMCNT(4);
     VITK_BARRIER();
     if (wm == 1) VITK_BARRIER();   // the second wave group runs one barrier behind the first
     int cur = 0;
@@ -518,6 +547,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #endif
             VITK_STAMP(0);
 
+            if constexpr (TWO_PHASE) {
+            // ---- phase A: rows 0-63 against the four column tiles.  Issues the A pieces of the cursor tile
+            // (their stage was last read in phase B of the previous K tile).  The B fragments read here are
+            // retired BEFORE the barrier: the other wave group restages those pieces in its next phase.
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    frag_b<B_KM>(fb0[jt][kb], lb, wn * 64, jt, kb, lane);
+                    frag_b<B_KM>(fb1[jt][kb], lb, wn * 64, 2 + jt, kb, lane);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) frag_a<A_KM>(fa[i][kb], la, wm * 128 + i * 16, kb, lane);
+            VITK_FENCE();
+            issue_slot(2);
+            issue_slot(3);
+            if (pf_live) VITK_VMCNT(8);     // phase B reads A q1 of this tile: behind it B (4) and A (4) of the tiles ahead
+            else VITK_VMCNT(0);
+            advance();
+            VITK_HALF(0, true);
+
+            // ---- phase B: rows 64-127.  Issues the B pieces of the (new) cursor tile into this tile's stage.
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) frag_a<A_KM>(fa[i][kb], la, wm * 128 + 64 + i * 16, kb, lane);
+            VITK_FENCE();
+            issue_slot(0);
+            issue_slot(1);
+            if (!pf_live) VITK_VMCNT(0);    // next phase A reads B and A q0 (K-major: all of A) of the next tile
+            else if (A_KM) VITK_VMCNT(4);
+            else VITK_VMCNT(6);
+            VITK_HALF(4, false);
+            } else {
             // ---- phase 0: quadrant (rows 0-63, tiles 0,1)
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
@@ -561,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             else if (B_KM) VITK_VMCNT(6);
             else VITK_VMCNT(8);
             VITK_QUADRANT(4, 0, fb0, 15, false);
+            }
             cur ^= 1;
         }
 
