@@ -122,6 +122,8 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=1)
     ap.add_argument('--cpu-layers', type=int, default=24)
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--graph', action='store_true',
+                    help='1 GPU: replay the step as one captured HIP graph (vit_amd.graph; the per-GEMM timer is off)')
     ap.add_argument('--force-reducer', action='store_true',
                     help='diagnostic: run the gradient reducer (flat slabs, hooks, all-reduce) even at world size 1')
     args = ap.parse_args()
@@ -154,7 +156,8 @@ def main():
     net = build_model(variant, preset, img_size=img, patch_size=patch, num_classes=classes,
                       mask_epochs=MASK_EPOCHS if 'lai' in variant else None, dtype=dtype, device=dev)
     from vit_amd.optim import AdamW
-    opt = AdamW(net.parameters(), lr=1e-4)
+    use_graph = args.graph and world == 1 and not args.force_reducer
+    opt = AdamW(net.parameters(), lr=1e-4, capturable=use_graph)
     reducer = None
     if world > 1 or args.force_reducer:
         from vit_amd.ddp import GradReducer
@@ -172,14 +175,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_graph:
+        from vit_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(net, opt, x, y, epoch=epoch, warmup=max(2, args.warmup))
+        step_fn = lambda: graphed.step(x, y)      # noqa: E731
+        args.no_kernel_timer = True
+    else:
+        step_fn = lambda: train_step(net, opt, x, y, epoch, reducer=reducer)      # noqa: E731
     for _ in range(args.warmup):
-        loss = train_step(net, opt, x, y, epoch, reducer=reducer)
+        loss = step_fn()
     timer = None if args.no_kernel_timer else []
     ops.KERNEL_TIMER = timer
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(net, opt, x, y, epoch, reducer=reducer)
+        loss = step_fn()
     barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
@@ -234,6 +244,7 @@ def main():
                                    f'{p["mlp"]} x {p["heads"]}h), {img}x{img}/{patch}, {N} tokens, LAI w={w}, '
                                    f'dropout 0, AdamW lr 1e-4, label smoothing 0.1',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'hip_graph': bool(use_graph),
                        'grad_bucket_mb': args.bucket_mb if world > 1 else None},
             'train_gflop_per_image': fl_img / 1e9, 'model_tflops_per_gpu': model_tflops_gpu,
             'mfma_roofline_frac_per_gpu': model_tflops_gpu / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16

@@ -76,7 +76,7 @@ int vitk_cast(int direction, long n, const void* src, void* dst, void* stream);
 
 /* One torch.optim.AdamW step (the optimizer train.py:275 builds and :549 steps; torch defaults
  * betas 0.9/0.999, eps 1e-8, weight_decay 1e-2) over one fp32 parameter viewed as [rows, cols]
- * (cols % 4 == 0), `step` counting from 1:
+ * (cols % 4 == 0 unless no copy is written), `step` counting from 1:
  *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
  * and, in the same pass, the bf16 copies of the new p that the GEMMs read: shadow [rows][ld_shadow]
@@ -84,6 +84,13 @@ int vitk_cast(int direction, long n, const void* src, void* dst, void* stream);
 int vitk_adamw(int rows, int cols, float* p, const float* g, float* m, float* v, double lr, double beta1,
                double beta2, double eps, double weight_decay, int step, void* shadow, long ld_shadow,
                void* shadow_t, long ld_shadow_t, void* stream);
+/* The same step with the step-dependent scalars read from device memory when the kernel runs:
+ * dyn[3] fp32 = {1 - lr*wd, lr/(1-b1^step), 1/sqrt(1-b2^step)}.  No counterpart in the reference: it
+ * lets the whole train step of train.py:530-554 be captured once in a HIP graph and replayed (the
+ * host rewrites dyn before each replay) -- for the launch-bound small configurations. */
+int vitk_adamw_dyn(int rows, int cols, float* p, const float* g, float* m, float* v, double beta1,
+                   double beta2, double eps, const float* dyn, void* shadow, long ld_shadow,
+                   void* shadow_t, long ld_shadow_t, void* stream);
 
 /* Patch gather / scatter for Conv2d(kernel = stride = P): out[(b*nph+ph)*npw+pw][(c*P+py)*P+px] =
  * img[b][c][ph*P+py][pw*P+px]  (model.py:92-99: proj(x).flatten(2).transpose(1,2)). */

@@ -26,6 +26,8 @@ _SIGNATURES = {
                             c_vp, c_vp, c_vp], c_int),
     'vitk_layernorm_bwd': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp,
                             c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp, c_vp], c_int),
+    'vitk_adamw_dyn': ([c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_double, c_vp,
+                        c_vp, c_long, c_vp, c_long, c_vp], c_int),
     'vitk_colsum': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_vp], c_int),
     'vitk_cast': ([c_int, c_long, c_vp, c_vp, c_vp], c_int),
     'vitk_adamw': ([c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_double, c_double, c_double, c_int,

@@ -1004,17 +1004,11 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
     if (dtype == VITK_BF16) {
         p.dq_acc = delta_end;
         p.ld_acc = HD;
-        if (hipMemsetAsync(p.dq_acc, 0, (size_t)rows * HD * 4, stream) != hipSuccess) {
-            vitk_set_error("vitk_attn_bwd: memset failed");
-            return VITK_ERR_LAUNCH;
-        }
+        if (vitk_zero_async(p.dq_acc, (size_t)HD * 4, (size_t)HD * 4, (size_t)rows, stream) != VITK_OK) return VITK_ERR_LAUNCH;
     } else {
         p.dq_acc = reinterpret_cast<float*>(dq);
         p.ld_acc = ld_d;
-        if (hipMemset2DAsync(dq, (size_t)ld_d * 4, 0, (size_t)HD * 4, (size_t)rows, stream) != hipSuccess) {
-            vitk_set_error("vitk_attn_bwd: memset2d failed");
-            return VITK_ERR_LAUNCH;
-        }
+        if (vitk_zero_async(dq, (size_t)ld_d * 4, (size_t)HD * 4, (size_t)rows, stream) != VITK_OK) return VITK_ERR_LAUNCH;
     }
     {
         const long total = rows * H;

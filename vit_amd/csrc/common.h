@@ -162,6 +162,10 @@ extern "C" void vitk_set_error(const char* fmt, ...);
         }                                \
     } while (0)
 
+// Zero-fill as a kernel of the library's own (runtime.hip) instead of hipMemsetAsync: an ordinary kernel node
+// when the stream is being captured into a HIP graph.  rows x row_bytes with a row pitch (pitch == row_bytes: flat).
+extern "C" int vitk_zero_async(void* ptr, size_t pitch, size_t row_bytes, size_t rows, hipStream_t stream);
+
 #define VITK_CHECK_LAUNCH(what)                                              \
     do {                                                                     \
         hipError_t e__ = hipGetLastError();                                  \

@@ -717,7 +717,7 @@ template <typename T, int DKB, int MT> void launch_fwd(const FavorParams& p, hip
     using C = ACfg<T, DKB>;
     constexpr int MTC = MT >= 4 ? 4 : 1;
     if (p.kind == FAVOR_SOFTMAX) {
-        (void)hipMemsetAsync(p.kmax, 0, 8, st);
+        (void)vitk_zero_async(p.kmax, 8, 8, 1, st);
         hipLaunchKernelGGL((favor_kmax_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), 0, st, p);
     }
     const size_t lds = (size_t)4 * 32 * C::ASTR * sizeof(T) + (size_t)(32 * DKB * (16 * MTC + 4) + 16 * MTC) * 4;
@@ -733,7 +733,7 @@ template <typename T, int DKB, int MT> void launch_fwd(const FavorParams& p, hip
 template <typename T, int DKB, int MT> void launch_bwd(const FavorParams& p, hipStream_t st) {
     using C = ACfg<T, DKB>;
     constexpr int MP = 16 * MT;
-    if (p.kind == FAVOR_SOFTMAX) (void)hipMemsetAsync(p.esum, 0, 4, st);
+    if (p.kind == FAVOR_SOFTMAX) (void)vitk_zero_async(p.esum, 4, 4, 1, st);
     const size_t lds_q = (size_t)(32 * DKB * (MP + 8) + 4 * 16 * C::ASTR) * sizeof(T) +
                          (size_t)(32 * DKB * (MP + 4) + MP + 4 * 64) * 4;
     const size_t lds_k = (size_t)(32 * DKB * (MP + 8)) * sizeof(T);

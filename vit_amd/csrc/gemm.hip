@@ -318,15 +318,9 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
                        "vitk_gemm: split-K needs an fp32 output and a linear epilogue");
         if (!accumulate) {
             if (ldc == N && grp_rows == 0) {
-                if (hipMemsetAsync(C, 0, (size_t)M * N * 4, stream) != hipSuccess) {
-                    vitk_set_error("vitk_gemm: memset failed");
-                    return VITK_ERR_LAUNCH;
-                }
+                if (vitk_zero_async(C, (size_t)N * 4, (size_t)N * 4, (size_t)M, stream) != VITK_OK) return VITK_ERR_LAUNCH;
             } else {
-                if (hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, stream) != hipSuccess) {
-                    vitk_set_error("vitk_gemm: memset2d failed");
-                    return VITK_ERR_LAUNCH;
-                }
+                if (vitk_zero_async(C, (size_t)ldc * 4, (size_t)N * 4, (size_t)M, stream) != VITK_OK) return VITK_ERR_LAUNCH;
             }
         }
     }

@@ -30,6 +30,7 @@ struct AdamWParams {
     float step_size;    // lr / (1 - b1^t)
     float inv_bc2_sqrt; // 1 / sqrt(1 - b2^t)
     float eps;
+    const float* dyn;   // optional device scalars {decay, step_size, inv_bc2_sqrt}: a captured HIP graph replays with new ones
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
@@ -38,28 +39,54 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
     const int r0 = blockIdx.y * OPT_TILE, c0 = blockIdx.x * OPT_TILE;
     const int cg = t & 15, rr = t >> 4;
     const int c = c0 + 4 * cg;
+    const float decay = a.dyn ? a.dyn[0] : a.decay;
+    const float step_size = a.dyn ? a.dyn[1] : a.step_size;
+    const float inv_bc2_sqrt = a.dyn ? a.dyn[2] : a.inv_bc2_sqrt;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int rl = rr + 16 * pass;
         const int r = r0 + rl;
         f32x4 pn = {0.f, 0.f, 0.f, 0.f};
-        if (r < a.rows && c < a.cols) {      // cols % 4 == 0 (host-checked): the whole vector is in range
+        if (r < a.rows && c < a.cols) {
             const long off = (long)r * a.cols + c;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + off);
-            f32x4 p = *reinterpret_cast<const f32x4*>(a.p + off);
-            f32x4 m = *reinterpret_cast<const f32x4*>(a.m + off);
-            f32x4 v = *reinterpret_cast<const f32x4*>(a.v + off);
+            const bool vec = (a.cols & 3) == 0;      // else (no copies, host-checked): element by element, ragged row end
+            f32x4 g = {0.f, 0.f, 0.f, 0.f}, p = g, m = g, v = g;
+            if (vec) {
+                g = *reinterpret_cast<const f32x4*>(a.g + off);
+                p = *reinterpret_cast<const f32x4*>(a.p + off);
+                m = *reinterpret_cast<const f32x4*>(a.m + off);
+                v = *reinterpret_cast<const f32x4*>(a.v + off);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < a.cols) {
+                        g[e] = a.g[off + e];
+                        p[e] = a.p[off + e];
+                        m[e] = a.m[off + e];
+                        v[e] = a.v[off + e];
+                    }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                p[e] *= a.decay;
+                p[e] *= decay;
                 m[e] += a.omb1 * (g[e] - m[e]);                       // torch: exp_avg.lerp_(grad, 1 - beta1)
                 v[e] = a.b2 * v[e] + a.omb2 * g[e] * g[e];
-                const float denom = sqrtf(v[e]) * a.inv_bc2_sqrt + a.eps;
-                p[e] -= a.step_size * (m[e] / denom);
+                const float denom = sqrtf(v[e]) * inv_bc2_sqrt + a.eps;
+                p[e] -= step_size * (m[e] / denom);
             }
-            *reinterpret_cast<f32x4*>(a.p + off) = p;
-            *reinterpret_cast<f32x4*>(a.m + off) = m;
-            *reinterpret_cast<f32x4*>(a.v + off) = v;
+            if (vec) {
+                *reinterpret_cast<f32x4*>(a.p + off) = p;
+                *reinterpret_cast<f32x4*>(a.m + off) = m;
+                *reinterpret_cast<f32x4*>(a.v + off) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < a.cols) {
+                        a.p[off + e] = p[e];
+                        a.m[off + e] = m[e];
+                        a.v[off + e] = v[e];
+                    }
+            }
             pn = p;
             if (a.shadow)
                 *reinterpret_cast<bf16x4*>(a.shadow + (long)r * a.ld_shadow + c) =
@@ -93,15 +120,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
 
 using namespace vitk;
 
-extern "C" int vitk_adamw(int rows, int cols, float* p, const float* g, float* m, float* v, double lr, double beta1,
-                          double beta2, double eps, double weight_decay, int step, void* shadow, long ld_shadow,
-                          void* shadow_t, long ld_shadow_t, hipStream_t stream) {
-    VITK_CHECK_ARG(rows >= 0 && cols >= 0 && cols % 4 == 0, "vitk_adamw: cols=%d must be a multiple of 4", cols);
+static int adamw_impl(int rows, int cols, float* p, const float* g, float* m, float* v, double lr, double beta1,
+                      double beta2, double eps, double weight_decay, int step, void* shadow, long ld_shadow,
+                      void* shadow_t, long ld_shadow_t, const float* dyn, hipStream_t stream) {
+    VITK_CHECK_ARG(rows >= 0 && cols >= 0, "vitk_adamw: negative shape");
+    VITK_CHECK_ARG(cols % 4 == 0 || (!shadow && !shadow_t), "vitk_adamw: cols=%d must be a multiple of 4 when copies are written", cols);
     VITK_CHECK_ARG(step >= 1, "vitk_adamw: step counts from 1");
     if (rows == 0 || cols == 0) return VITK_OK;
     VITK_CHECK_ARG(p && g && m && v, "vitk_adamw: null tensor");
     auto al = [](const void* q, int a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-    VITK_CHECK_ARG(al(p, 16) && al(g, 16) && al(m, 16) && al(v, 16), "vitk_adamw: tensors must be 16-byte aligned");
+    VITK_CHECK_ARG(cols % 4 != 0 || (al(p, 16) && al(g, 16) && al(m, 16) && al(v, 16)),
+                   "vitk_adamw: tensors must be 16-byte aligned");
     VITK_CHECK_ARG(!shadow || (ld_shadow >= cols && ld_shadow % 4 == 0 && al(shadow, 8)),
                    "vitk_adamw: shadow needs ld >= cols, ld %% 4 == 0 and 8-byte alignment");
     VITK_CHECK_ARG(!shadow_t || (ld_shadow_t >= rows && al(shadow_t, 16)),
@@ -121,9 +150,28 @@ extern "C" int vitk_adamw(int rows, int cols, float* p, const float* g, float* m
     a.step_size = (float)(lr / bc1);
     a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     a.eps = (float)eps;
+    a.dyn = dyn;
     const dim3 grid((cols + OPT_TILE - 1) / OPT_TILE, (rows + OPT_TILE - 1) / OPT_TILE);
     VITK_CHECK_ARG(grid.y <= 65535, "vitk_adamw: too many rows");
     hipLaunchKernelGGL(adamw_kernel, grid, dim3(256), 0, stream, a);
     VITK_CHECK_LAUNCH("vitk_adamw");
     return VITK_OK;
+}
+
+extern "C" int vitk_adamw(int rows, int cols, float* p, const float* g, float* m, float* v, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, int step, void* shadow, long ld_shadow,
+                          void* shadow_t, long ld_shadow_t, hipStream_t stream) {
+    return adamw_impl(rows, cols, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, shadow, ld_shadow, shadow_t,
+                      ld_shadow_t, nullptr, stream);
+}
+
+// The same step with the three step-dependent scalars read from DEVICE memory at run time:
+// dyn = {1 - lr*wd, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} (fp32).  For a training step captured in a HIP
+// graph: the host rewrites dyn before every replay, the captured launch stays valid.
+extern "C" int vitk_adamw_dyn(int rows, int cols, float* p, const float* g, float* m, float* v, double beta1,
+                              double beta2, double eps, const float* dyn, void* shadow, long ld_shadow,
+                              void* shadow_t, long ld_shadow_t, hipStream_t stream) {
+    VITK_CHECK_ARG(dyn != nullptr, "vitk_adamw_dyn: null dyn");
+    return adamw_impl(rows, cols, p, g, m, v, 0.0, beta1, beta2, eps, 0.0, 1, shadow, ld_shadow, shadow_t, ld_shadow_t,
+                      dyn, stream);
 }

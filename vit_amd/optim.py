@@ -26,18 +26,41 @@ _torch_adamw = importlib.import_module('torch.optim.adamw').adamw     # function
 
 class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *,
-                 maximize=False):
+                 maximize=False, capturable=False):
         if amsgrad or maximize:
             raise ValueError('vit_amd.optim.AdamW: amsgrad / maximize are not implemented (the reference uses neither)')
         if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError('vit_amd.optim.AdamW: invalid hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        # capturable: every step-dependent scalar lives in device memory (vitk_adamw_dyn) and EVERY fp32 parameter,
+        # 1-D ones included, goes through the HIP kernel, so that step() can be captured in a HIP graph
+        # (vit_amd/graph.py); update_dyn() must then run before each step / graph replay.
+        self.capturable = bool(capturable)
+        self._t = 0
 
-    @staticmethod
-    def _native(p):
-        """Parameters the HIP kernel updates: fp32, on the GPU, >= 2-D, rows of whole 16-byte vectors."""
-        return (p.is_cuda and p.dtype == torch.float32 and p.dim() >= 2 and p.is_contiguous()
-                and p.shape[0] > 0 and (p.numel() // p.shape[0]) % 4 == 0 and p.data_ptr() % 16 == 0)
+    def update_dyn(self):
+        """Advance the step count and write each group's {1 - lr wd, lr / (1 - b1^t), 1 / sqrt(1 - b2^t)} to its device
+        scalars (a stream-ordered host-to-device copy: legal right before a graph replay, not inside a capture)."""
+        self._t += 1
+        for group in self.param_groups:
+            b1, b2 = group['betas']
+            vals = [1.0 - group['lr'] * group['weight_decay'], group['lr'] / (1.0 - b1 ** self._t),
+                    1.0 / (1.0 - b2 ** self._t) ** 0.5]
+            if 'dyn' not in group:
+                dev = group['params'][0].device
+                group['dyn'] = torch.zeros(3, device=dev, dtype=torch.float32)
+                group['dyn_host'] = torch.zeros(3, dtype=torch.float32).pin_memory()
+            group['dyn_host'].copy_(torch.tensor(vals, dtype=torch.float64).to(torch.float32))
+            group['dyn'].copy_(group['dyn_host'], non_blocking=True)
+
+    def _native(self, p):
+        """Parameters the HIP kernel updates: fp32, on the GPU, >= 2-D (capturable: any rank, a 1-D parameter
+        is one row), rows of whole 16-byte vectors."""
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.numel() > 0 and p.data_ptr() % 16 == 0):
+            return False
+        if p.dim() < 2:
+            return self.capturable          # one row; a ragged length takes the kernel's element-wise form
+        return (p.numel() // p.shape[0]) % 4 == 0
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -46,11 +69,11 @@ class AdamW(torch.optim.Optimizer):
     def _plan(self, p, st):
         """Launch arguments of one native parameter that do not change from step to step (everything
         but the gradient pointer): valid while functional's set of cached copies is unchanged."""
-        rows = p.shape[0]
+        rows = p.shape[0] if p.dim() >= 2 else 1
         cols = p.numel() // rows
         ps = lds = pt = ldt = 0
         for key, buf, off, transposed in VF.shadow_targets(p):
-            ok = buf.dtype == torch.bfloat16 and buf.is_contiguous() and buf.numel() > 0
+            ok = buf.dtype == torch.bfloat16 and buf.is_contiguous() and buf.numel() > 0 and p.dim() >= 2
             if ok and not transposed and not ps and buf.numel() // buf.shape[0] == cols and cols % 4 == 0 \
                     and off + rows <= buf.shape[0]:
                 lds = cols
@@ -98,7 +121,8 @@ class AdamW(torch.optim.Optimizer):
                     small_v.append(st['exp_avg_sq'])
                     small_t.append(st['step'])
                     continue
-                st['step'] += 1
+                if not self.capturable:
+                    st['step'] += 1
                 if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16 or g.shape != p.shape:
                     g = g.float().contiguous().clone().view_as(p)
                 plan = plans.get(id(p))
@@ -107,8 +131,17 @@ class AdamW(torch.optim.Optimizer):
                 if stream is None:
                     stream = _stream()
                 rows, cols, pp, pm, pv, ps, lds, pt, ldt = plan
-                check(L.vitk_adamw(rows, cols, pp, g.data_ptr(), pm, pv, lr, b1, b2, eps, wd, int(st['step']),
-                                   ps, lds, pt, ldt, stream), 'vitk_adamw')
+                if self.capturable:
+                    if 'dyn' not in group:
+                        raise RuntimeError('vit_amd.optim.AdamW(capturable=True): call update_dyn() before step()')
+                    check(L.vitk_adamw_dyn(rows, cols, pp, g.data_ptr(), pm, pv, b1, b2, eps, group['dyn'].data_ptr(),
+                                           ps, lds, pt, ldt, stream), 'vitk_adamw_dyn')
+                else:
+                    check(L.vitk_adamw(rows, cols, pp, g.data_ptr(), pm, pv, lr, b1, b2, eps, wd, int(st['step']),
+                                       ps, lds, pt, ldt, stream), 'vitk_adamw')
+            if small and self.capturable:
+                raise RuntimeError('vit_amd.optim.AdamW(capturable=True): every parameter must be fp32 on the GPU with a '
+                                   'multiple of 4 elements per row (>= 2-D); got %s' % [tuple(q.shape) for q in small])
             if small:
                 if small[0].is_cuda:
                     _torch_adamw(small, small_g, small_m, small_v, [], small_t, amsgrad=False, beta1=b1,
