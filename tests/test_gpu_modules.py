@@ -209,3 +209,30 @@ def test_vit_lai_model_vs_oracle(dtype):
             assert relerr(p.grad.cpu(), rp[n].grad) < tol, (ep, n)
             p.grad = None
             rp[n].grad = None
+
+
+def test_headline_size_batch_independence_and_grad_sum():
+    """Full BASELINE size (B = 128 x 197 tokens, D = 1024, 16 heads, LAI w = 20, bf16), where the oracle is too
+    slow: size-independent properties of a data-parallel path.  (1) Batch independence: sample b of the batch of
+    128 gives the output it gives in a batch of 2 (other tiles, other workgroups, same arithmetic).
+    (2) Gradient additivity: parameter gradients of the batch = the sum over two half batches."""
+    from vit_amd.train import build_model
+    torch.manual_seed(3)
+    net = build_model('disentangled_lai_attention', 'B', mask_epochs=[10, 20, 30, 40], depth=2, num_classes=1000)
+    img = torch.randn(128, 3, 224, 224, device='cuda')
+    w = torch.randn(128, 1000, device='cuda')
+    out = net(img, 30)
+    pick = torch.tensor([0, 127], device='cuda')
+    small = net(img[pick], 30)
+    assert relerr(out[pick].detach().cpu(), small.detach().cpu().numpy()) < 2e-2
+    (out.float() * w).sum().backward()
+    full = {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    for half in (slice(0, 64), slice(64, 128)):
+        (net(img[half], 30).float() * w[half]).sum().backward()
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = p.grad.detach().float(), full[n]
+        l2 = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+        assert l2 < 3e-2, (n, l2)      # bf16 activations; fp32 accumulation in another order
