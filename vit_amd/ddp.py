@@ -4,8 +4,11 @@ utils/ops.py:124-133) on one 8 x MI355X node: one process per GPU, RCCL over xGM
 (torch.distributed backend "nccl" on ROCm; "gloo" for CPU rehearsals).
 
 Design (MI355X first, not a DDP translation):
-  * gradients LIVE in a few large flat fp32 slabs: every used parameter's ``.grad`` is a view
-    into its bucket, so backward writes land in the slab and no copy-in / copy-out pass exists;
+  * gradients LIVE in a few large flat fp32 slabs: every used parameter's ``.grad`` is a view into
+    its bucket.  The fused blocks' weight-gradient GEMMs write straight into those views
+    (functional.grad_slot: a zeroed view, handed out once per step); any other gradient is
+    copied into its view by the post-accumulate hook -- one copy, where accumulating into
+    pre-zeroed views cost a zero-fill plus a read-modify-write of the whole gradient;
   * buckets follow REVERSE registration order (the order backward produces gradients) and are
     sized for xGMI: 7 point-to-point links x ~153 GB/s per GPU make a ring all-reduce per-link
     bound, so few, large (default 128 MiB) collectives amortise latency while still leaving
@@ -34,6 +37,7 @@ class GradReducer:
         self.buckets = []        # flat fp32 tensors
         self._pending = []       # per bucket: parameters still missing this step
         self._bucket_of = {}
+        self._view_of = {}
         self._handles = []
         self._hooks = []
         self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == 'nccl' else dist.ReduceOp.SUM
@@ -78,6 +82,7 @@ class GradReducer:
                 view = flat[off:off + p.numel()].view_as(p)
                 view.copy_(p.grad)
                 p.grad = view
+                self._view_of[p] = view
                 self._bucket_of[p] = bi
                 off += (p.numel() + 63) // 64 * 64
             self.buckets.append(flat)
@@ -87,6 +92,12 @@ class GradReducer:
         self.built = True
 
     def _on_grad(self, p):
+        view = self._view_of[p]
+        g = p.grad
+        if g is not view and g.data_ptr() != view.data_ptr():     # produced elsewhere: into the slab, once
+            view.copy_(g)
+            p.grad = view
+        p._vitk_grad_slot = None
         bi = self._bucket_of[p]
         pend = self._pending[bi]
         pend.discard(p)
@@ -107,8 +118,15 @@ class GradReducer:
                 p.grad = None
             self._launched = None
             return
-        for flat in self.buckets:
-            flat.zero_()
+        # No slab-wide zero-fill: every view is either written whole by the hook's copy or zeroed here because
+        # a GEMM will accumulate into it (the slot protocol of functional.grad_slot); the pads were zeroed at build.
+        for ps in self._groups:
+            for p in ps:
+                p.grad = None
+                if getattr(p, '_vitk_direct', False):       # set by the fused blocks on the weights they can write in place
+                    view = self._view_of[p]
+                    view.zero_()
+                    p._vitk_grad_slot = view
         self._pending = [set(ps) for ps in self._groups]
         self._launched = [False] * len(self.buckets)
 
@@ -120,6 +138,10 @@ class GradReducer:
             self._launched = [False] * len(self.buckets)
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:       # a parameter got no gradient this step: reduce zeros for it
+                for p in self._pending[bi]:
+                    self._view_of[p].zero_()
+                    p.grad = self._view_of[p]
+                    p._vitk_grad_slot = None
                 self._launch(bi)
         for h in self._handles:
             h.wait()

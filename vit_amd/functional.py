@@ -136,6 +136,18 @@ class _ZeroPool:
         return v
 
 
+def grad_slot(param):
+    """The zeroed view of the data-parallel reducer's gradient slab that the weight gradient of ``param`` may be
+    accumulated into, when the reducer offered one for this step (ddp.GradReducer.prepare; taken at most
+    once) -- else None (the caller uses a zeroed slice of its pool).  Marks the parameter as able to take one."""
+    param._vitk_direct = True
+    slot = getattr(param, '_vitk_grad_slot', None)
+    if slot is not None and slot.dtype == torch.float32 and slot.shape == param.shape:
+        param._vitk_grad_slot = None
+        return slot
+    return None
+
+
 def _dw(dy, x, out=None):
     """dW[out, in] = dy^T x in fp32 (split-K over the token dimension).  ``out``: a ZEROED fp32 buffer to
     add into (a slice of the block's one zero-filled pool: the split-K atomics then need no memset of
@@ -433,17 +445,27 @@ class DisLayerFn(torch.autograd.Function):
         dy = dy.contiguous()
         F = wi.shape[0]
         R = band.shape[0] if band is not None else 0
-        zp = _ZeroPool(x_ext.device, D, D, D, D, D, D, D, F, D, 3 * D, R * 2 * D, F * D, D * F, D * D, 3 * D * D)
+        direct = dt == torch.bfloat16      # the fp32 path's dW GEMMs allocate their own outputs
+        s_wi, s_wout, s_wo = (grad_slot(q) if direct else None for q in (wi, wout, wo))
+        zp = _ZeroPool(x_ext.device, D, D, D, D, D, D, D, F, D, 3 * D, R * 2 * D, 3 * D * D,
+                       0 if s_wi is not None else F * D, 0 if s_wout is not None else D * F, 0 if s_wo is not None else D * D)
         dg2, dbe2, dbout = zp.take(D), zp.take(D), zp.take(D)
         ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2, dxsum=dbout)
         da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, wi, wout, act, hmid, pre, ds2,
                                               db1=zp.take(F), db2=dbout, db2_done=True,
-                                              dw1=zp.take(F, D), dw2=zp.take(D, F))
+                                              dw1=s_wi if s_wi is not None else zp.take(F, D),
+                                              dw2=s_wout if s_wout is not None else zp.take(D, F))
+        if dwi is s_wi:
+            dwi = dwi.detach()          # a fresh alias of the slab view: autograd adopts it as .grad without a copy
+        if dwout is s_wout:
+            dwout = dwout.detach()
         dg1, dbe1, dbo = zp.take(D), zp.take(D), zp.take(D)
         ds1_ext = _ext_workspace('ds1', ME, D, dt, x_ext.device) if band is not None else \
             torch.empty(ME, D, device=x_ext.device, dtype=dt)
         ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
-        dwo = _dw(ds1, attn, out=zp.take(D, D))
+        dwo = _dw(ds1, attn, out=s_wo if s_wo is not None else zp.take(D, D))
+        if dwo is s_wo:
+            dwo = dwo.detach()
         dattn = _dx(ds1, wo)
         tables = dtab = None
         if band is not None:
