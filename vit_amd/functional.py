@@ -339,16 +339,25 @@ class PreLNBlockFn(torch.autograd.Function):
         dt = x.dtype
         dy = dy.contiguous()
         F = w1.shape[0]
-        zp = _ZeroPool(x.device, D, D, D, D, D, D, F, D, 3 * D, F * D, D * F, D * D, 3 * D * D)
+        direct = dt == torch.bfloat16      # the fp32 path's dW GEMMs allocate their own outputs
+        s_w1, s_w2, s_wproj, s_wqkv = (grad_slot(q) if direct else None for q in (w1, w2, wproj, wqkv))
+        zp = _ZeroPool(x.device, D, D, D, D, D, D, F, D, 3 * D,
+                       0 if s_w1 is not None else F * D, 0 if s_w2 is not None else D * F,
+                       0 if s_wproj is not None else D * D, 0 if s_wqkv is not None else 3 * D * D)
         dh2, dw1, db1, dw2, db2 = _mlp_bwd(dy, h2, w1, w2, act, hmid, pre, None,
-                                           db1=zp.take(F), db2=zp.take(D), dw1=zp.take(F, D), dw2=zp.take(D, F))
+                                           db1=zp.take(F), db2=zp.take(D),
+                                           dw1=s_w1 if s_w1 is not None else zp.take(F, D),
+                                           dw2=s_w2 if s_w2 is not None else zp.take(D, F))
         dg2, dbe2, dbproj = zp.take(D), zp.take(D), zp.take(D)
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy, dxsum=dbproj)
-        dwproj = _dw(dx1, attn, out=zp.take(D, D))
+        dwproj = _dw(dx1, attn, out=s_wproj if s_wproj is not None else zp.take(D, D))
         dattn = _dx(dx1, wproj)
         dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse)
         dbqkv = ops.colsum(dqkv, out=zp.take(3 * D)) if ctx.has_qkv_bias else None
-        dwqkv = _dw(dqkv, h1, out=zp.take(3 * D, D))
+        dwqkv = _dw(dqkv, h1, out=s_wqkv if s_wqkv is not None else zp.take(3 * D, D))
+        # a fresh alias of a slab view: autograd adopts it as .grad without a copy
+        dw1, dw2, dwproj, dwqkv = (t.detach() if t is s else t
+                                   for t, s in ((dw1, s_w1), (dw2, s_w2), (dwproj, s_wproj), (dwqkv, s_wqkv)))
         dh1 = _dx(dqkv, wqkv)
         dg1, dbe1 = zp.take(D), zp.take(D)
         dx = ops.layernorm_bwd(dh1, x, mean1, rstd1, _f32(g1), dg1, dbe1, add=dx1)
