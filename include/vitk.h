@@ -148,6 +148,35 @@ int vitk_favor_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, cons
                    const void* dout, long ldo, void* dq, void* dk, void* dv, long ld_d, void* workspace,
                    void* stream);
 
+/* FAVOR+ with position features: DisentangledSelfAttentionPerformer.forward
+ * (disentangled_transformer/disentangled_transformer.py:496-610) with
+ * disentangled_attention_perf_bias :612-644 and the class's own feature maps :717-749 (the same
+ * quirks as above: unscaled projection, diag from the plain sum, global key max, eps inside the ratio):
+ *     new_Q = q' + Pq,  new_K = k' + Pk,  out = new_Q (new_K^T v) / (new_Q . sum_l new_K)
+ * Pq / Pk = query- / key-form feature maps of pos_query_proj / pos_key_proj(pos_embed), one [L][H][m]
+ * table each, the same for every batch element.
+ * vitk_favor_feature_pitch(m): row pitch mp (floats) of every table below.
+ * vitk_favor_pos_fwd: x [L, ld] (T) -> feat fp32 [L][H][mp]; is_query picks the row max (:732) or the
+ *   max over the whole table (:736) as stabiliser; `state` (>= 16 bytes, 16-byte aligned) keeps the key
+ *   max / argmax for the backward.
+ * vitk_favor_pos_attn_fwd / _bwd: vitk_favor_fwd / _bwd with the tables added; the backward also fills
+ *   dnq / dnk (fp32 [B][L][H][mp]) with d loss / d new_Q and d new_K per batch element.
+ * vitk_favor_pos_bwd: sums dfeat over its first dim (nsum = B) and goes back through the feature map,
+ *   both maxima included: dx [L, ld_d] (T). */
+int vitk_favor_feature_pitch(int m);
+int vitk_favor_pos_fwd(int dtype, int kind, int is_query, int H, int L, int dh, int m, const void* x, long ld,
+                       const void* w, float ratio, float eps, float* feat, void* state, void* stream);
+int vitk_favor_pos_bwd(int dtype, int kind, int is_query, int nsum, int H, int L, int dh, int m, const void* x,
+                       long ld, const void* w, float ratio, float eps, const float* dfeat, void* dx, long ld_d,
+                       void* state, void* stream);
+int vitk_favor_pos_attn_fwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                            const void* v, long ld, const void* w, float ratio, float eps, const float* pq,
+                            const float* pk, void* out, long ldo, void* workspace, void* stream);
+int vitk_favor_pos_attn_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                            const void* v, long ld, const void* w, float ratio, float eps, const float* pq,
+                            const float* pk, const void* out, const void* dout, long ldo, void* dq, void* dk,
+                            void* dv, long ld_d, float* dnq, float* dnk, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -462,6 +462,66 @@ class RefPerformerAttention(nn.Module):
         return self.proj(favor_linear_attention(qp, kp, v).flatten(-2))
 
 
+class RefDisentangledSelfAttentionPerformer(nn.Module):
+    """DisentangledSelfAttentionPerformer (disentangled_transformer/disentangled_transformer.py:431-785),
+    live code only (:586-602 + :612-644; the CC/CP/PC block :535-584 is a string literal).
+    new_Q = q' + Pq, new_K = k' + Pk; Pq / Pk = query / key feature maps of
+    pos_query_proj / pos_key_proj(pos_embed) with batch 1 (so the key-side "whole tensor" max is over
+    [1,L,H,m]), broadcast over the batch.  The class's feature maps (:717-749) are the same formulas as
+    timm_vision_performer's, ratio m^-1/4 for both kernels.  ``w`` is an explicit attribute ([m, dh])."""
+
+    def __init__(self, d_model=512, nhead=8, norf=32, kernel='softmax'):
+        super().__init__()
+        self.num_attention_heads, self.m, self.kernel = nhead, int(norf), kernel
+        self.query_proj = nn.Linear(d_model, d_model)
+        self.key_proj = nn.Linear(d_model, d_model)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.pos_key_proj = nn.Linear(d_model, d_model)
+        self.pos_query_proj = nn.Linear(d_model, d_model)
+        self.w = None
+
+    def features(self, data, is_query):
+        ratio = self.m ** -0.25
+        if self.kernel == 'softmax':
+            return favor_softmax_features(data, self.w, is_query, ratio)
+        return favor_relu_features(data, self.w, ratio)
+
+    def forward(self, q, k, value, relative_pos=None, rel_embeddings=None, query=None, pos_embed=None):
+        B, L, D = q.shape
+        H = self.num_attention_heads
+        if self.w is None:
+            self.w = gaussian_orthogonal_random_matrix(self.m, D // H).to(q.device)
+
+        def heads(t):
+            return t.reshape(t.shape[0], t.shape[1], H, D // H)
+        Q, K, V = heads(self.query_proj(q)), heads(self.key_proj(k)), heads(self.value_proj(value))
+        kp, qp = self.features(K, False), self.features(Q, True)
+        pos = pos_embed.permute(1, 0, 2)                                   # [L,1,D] -> [1,L,D]  (:614)
+        Pk = self.features(heads(self.pos_key_proj(pos)), False)           # [1,L,H,m]
+        Pq = self.features(heads(self.pos_query_proj(pos)), True)
+        ctx = favor_linear_attention(qp + Pq, kp + Pk, V).flatten(-2)
+        return {'hidden_states': ctx, 'attention_probs': None, 'attention_logits': None}
+
+
+class RefDisentangledPerformerLayer(nn.Module):
+    """DisentangledEncoderLayer (:130-246) with performers=True: the same post-LN block around the
+    attention above; pos_embed is handed through (:213-215)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, norf=32, kernel='softmax'):
+        super().__init__()
+        self.dis_attn = RefDisentangledSelfAttentionPerformer(d_model, nhead, norf, kernel)
+        self.dense_AttnOut = nn.Linear(d_model, d_model)
+        self.layer_norm_AttnOut = nn.LayerNorm(d_model)
+        self.dense_intermediate = nn.Linear(d_model, dim_feedforward)
+        self.dense_out = nn.Linear(dim_feedforward, d_model)
+        self.layer_norm_out = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos_embed):
+        ctx = self.dis_attn(src, src, src, pos_embed=pos_embed)['hidden_states']
+        a = self.layer_norm_AttnOut(self.dense_AttnOut(ctx) + src)
+        return self.layer_norm_out(self.dense_out(F.gelu(self.dense_intermediate(a))) + a)
+
+
 class RefMultiheadAttentionPerformer(nn.MultiheadAttention):
     """MultiheadAttentionPerformer (model.py:248-388): [L,B,E] layout, packed in_proj,
     softmax-kernel ratio m^-1/2 (:323) but relu-kernel ratio m^-1/4 (:347)."""

@@ -155,6 +155,65 @@ def test_performer_mha():
             close(v, g[pre + k], what=pre + k, rtol=5e-5)
 
 
+DISPERF_SHAPES = (('a', 2, 65, 128, 4, 16), ('b', 2, 145, 256, 4, 64), ('c', 3, 50, 96, 2, 40))
+
+
+def test_dis_performer_attention():
+    """RefDisentangledSelfAttentionPerformer vs the reference's DisentangledSelfAttentionPerformer
+    (dis :431), outputs and every gradient incl. d pos_embed."""
+    g = load('dis_performer.npz')
+    for name, B, N, D, H, m in DISPERF_SHAPES:
+        x = gi.randn(61, 'x_' + name, B, N, D)
+        pos0 = gi.randn(61, 'pos_' + name, N, 1, D, scale=0.5)
+        for kernel in ('softmax', 'relu'):
+            mod = R.RefDisentangledSelfAttentionPerformer(D, H, norf=m, kernel=kernel)
+            mod.load_state_dict(gi.fill_state_dict(mod.state_dict(), seed=62))
+            pre = f'attn_{name}_{kernel}_'
+            mod.w = torch.from_numpy(g[pre + 'w'])
+            pos = pos0.clone().requires_grad_(True)
+            r = run_with_grads(lambda t: mod(t, t, t, pos_embed=pos)['hidden_states'], x,
+                               list(mod.named_parameters()), 64, 1)
+            r['d_pos'] = gi.sub(pos.grad, 1).numpy()
+            assert set(r) == set(k[len(pre):] for k in g.files if k.startswith(pre)) - {'w'}
+            for k, v in r.items():
+                close(v, g[pre + k], what=pre + k, rtol=5e-5)
+
+
+def test_dis_performer_layer():
+    g = load('dis_performer.npz')
+    B, N, D, H, m = 2, 65, 128, 4, 32
+    x = gi.randn(65, 'x_layer', B, N, D)
+    pos0 = gi.randn(65, 'pos_layer', N, 1, D, scale=0.5)
+    for kernel in ('softmax', 'relu'):
+        lay = R.RefDisentangledPerformerLayer(D, H, 256, norf=m, kernel=kernel)
+        sd = gi.fill_state_dict({k: torch.empty(v) for k, v in DISPERF_LAYER_KEYS(D, 256).items()}, seed=66)
+        lay.load_state_dict({k: v for k, v in sd.items() if k in lay.state_dict()})
+        pre = f'layer_{kernel}_'
+        lay.dis_attn.w = torch.from_numpy(g[pre + 'w'])
+        pos = pos0.clone().requires_grad_(True)
+        r = run_with_grads(lambda t: lay(t, pos), x, list(lay.named_parameters()), 68, 1)
+        r['d_pos'] = gi.sub(pos.grad, 1).numpy()
+        assert set(r) == set(k[len(pre):] for k in g.files if k.startswith(pre)) - {'w'}
+        for k, v in r.items():
+            close(v, g[pre + k], what=pre + k, rtol=5e-5)
+
+
+def DISPERF_LAYER_KEYS(D, F):
+    """state_dict shapes of the reference's DisentangledEncoderLayer(performers=True) (values in the
+    fixtures depend on key names only: golden_inputs.fill_state_dict)."""
+    shapes = {}
+    for lin, (o, i) in {'dis_attn.query_proj': (D, D), 'dis_attn.key_proj': (D, D), 'dis_attn.value_proj': (D, D),
+                        'dis_attn.pos_key_proj': (D, D), 'dis_attn.pos_query_proj': (D, D), 'query_proj': (D, D),
+                        'key_proj': (D, D), 'value_proj': (D, D), 'dense_AttnOut': (D, D),
+                        'dense_intermediate': (F, D), 'dense_out': (D, F)}.items():
+        shapes[lin + '.weight'] = (o, i)
+        shapes[lin + '.bias'] = (o,)
+    for ln in ('layer_norm_AttnOut', 'layer_norm_out'):
+        shapes[ln + '.weight'] = (D,)
+        shapes[ln + '.bias'] = (D,)
+    return shapes
+
+
 def test_orthogonal_features_shape():
     w = R.gaussian_orthogonal_random_matrix(80, 32, generator=torch.Generator().manual_seed(0))
     assert w.shape == (80, 32)

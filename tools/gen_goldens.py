@@ -230,6 +230,69 @@ def gen_performer(Attention):
     np.savez_compressed(os.path.join(OUT, 'performer.npz'), **out)
 
 
+def gen_dis_performer():
+    """DisentangledSelfAttentionPerformer (dis :431) alone, one DisentangledEncoderLayer(performers=True),
+    and a 2-layer model through model.VisionTransformer (train.py:215-234's wiring); ``w`` drawn by the
+    reference's own generator under a fixed seed and stored."""
+    from disentangled_transformer.disentangled_transformer import (
+        DisentangledSelfAttentionPerformer, DisentangledEncoderLayer, DisentangledTransformer)
+    import model as M
+    out = {}
+    for name, B, N, D, H, m in (('a', 2, 65, 128, 4, 16), ('b', 2, 145, 256, 4, 64), ('c', 3, 50, 96, 2, 40)):
+        x = gi.randn(61, 'x_' + name, B, N, D)
+        pos0 = gi.randn(61, 'pos_' + name, N, 1, D, scale=0.5)
+        for kernel in ('softmax', 'relu'):
+            mod = DisentangledSelfAttentionPerformer(D, H, dropout=0.0, relative_attention=True,
+                                                     max_position_embeddings=D, norf=m, kernel=kernel)
+            mod.load_state_dict(gi.fill_state_dict(mod.state_dict(), seed=62))
+            torch.manual_seed(63)
+            mod.w = mod.gaussian_orthogonal_random_matrix(m, D // H)
+            pos = pos0.clone().requires_grad_(True)
+            r = run_with_grads(lambda t: mod(t, t, t, pos_embed=pos)['hidden_states'], x,
+                               list(mod.named_parameters()), 64, 1)
+            r['d_pos'] = np_(gi.sub(pos.grad, 1))
+            r['w'] = np_(mod.w)
+            for k, v in r.items():
+                out[f'attn_{name}_{kernel}_{k}'] = v
+    # one encoder layer
+    B, N, D, H, m = 2, 65, 128, 4, 32
+    x = gi.randn(65, 'x_layer', B, N, D)
+    pos0 = gi.randn(65, 'pos_layer', N, 1, D, scale=0.5)
+    for kernel in ('softmax', 'relu'):
+        lay = DisentangledEncoderLayer(d_model=D, nhead=H, dropout=0.0, relative_attention=True,
+                                       max_position_embeddings=D, dim_feedforward=256, performers=True,
+                                       norf=m, kernel=kernel)
+        lay.load_state_dict(gi.fill_state_dict(lay.state_dict(), seed=66))
+        torch.manual_seed(67)
+        lay.dis_attn.w = lay.dis_attn.gaussian_orthogonal_random_matrix(m, D // H)
+        pos = pos0.clone().requires_grad_(True)
+        r = run_with_grads(lambda t: lay(t, pos_embed=pos), x, list(lay.named_parameters()), 68, 1)
+        r['d_pos'] = np_(gi.sub(pos.grad, 1))
+        r['w'] = np_(lay.dis_attn.w)
+        for k, v in r.items():
+            out[f'layer_{kernel}_{k}'] = v
+    # 2-layer model (N = 65, D = 128)
+    tr = DisentangledTransformer(d_model=128, dropout=0.0, nhead=4, dim_feedforward=256, num_encoder_layers=2,
+                                 normalize_before=True, pos_att_type='c2p|p2c', max_position_embeddings=128,
+                                 relative_attention=True, performers=True, norf=16, kernel='softmax')
+    net = M.VisionTransformer(img_size=32, patch_size=4, in_chans=3, num_classes=10, transformer=tr)
+    net.load_state_dict(gi.fill_state_dict(net.state_dict(), seed=71))
+    torch.manual_seed(72)
+    for i, lay in enumerate(tr.encoder.layers):
+        lay.dis_attn.w = lay.dis_attn.gaussian_orthogonal_random_matrix(16, 32)
+        out[f'model_w{i}'] = np_(lay.dis_attn.w)
+    img = gi.randn(71, 'img', 2, 3, 32, 32)
+    r = run_with_grads(lambda t: net(t), img, list(net.named_parameters()), 73, 1)
+    keep = ['y', 'dx', 'd_pos_embed', 'd_transformer.encoder.layers.0.dis_attn.query_proj.weight',
+            'd_transformer.encoder.layers.1.dis_attn.pos_key_proj.weight',
+            'd_transformer.encoder.layers.0.dis_attn.pos_query_proj.bias',
+            'd_transformer.encoder.layers.1.dense_out.weight', 'd_patch_embed.proj.weight', 'd_cls_token']
+    for k in keep:
+        out['model_' + k] = r[k]
+    out['model_nograd'] = np.array([n for n, p in net.named_parameters() if ('d_' + n) not in r], dtype='U')
+    np.savez_compressed(os.path.join(OUT, 'dis_performer.npz'), **out)
+
+
 def gen_config1():
     """BASELINE config 1: regular ViT, CIFAR 32x32, patch 4, 6 layers, dim 256, 8 heads,
     one fwd/bwd/AdamW step (train.py:530-554 restated: timm LabelSmoothingCrossEntropy(0.1),
@@ -262,12 +325,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     Attention = install_shims()
     torch.set_num_threads(8)
-    gen_masks()
-    gen_lai_attention()
-    gen_dis_attention()
-    gen_dis_model()
-    gen_performer(Attention)
-    gen_config1()
+    gens = {'masks': gen_masks, 'lai_attention': gen_lai_attention, 'dis_attention': gen_dis_attention,
+            'dis_model': gen_dis_model, 'performer': lambda: gen_performer(Attention),
+            'dis_performer': gen_dis_performer, 'config1': gen_config1}
+    for name in (sys.argv[1:] or list(gens)):      # optional: only the named fixtures
+        gens[name]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

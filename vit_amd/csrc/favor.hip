@@ -46,6 +46,10 @@ struct FavorParams {
     float* esum;            // global sum of the key-side exp gradients
     void *dq, *dk, *dv;
     long ld_d;
+    // position features (DisentangledSelfAttentionPerformer): q' += pq[l][h][.], k' += pk[l][h][.]  (fp32 [L][H][mp],
+    // the same for every b); the backward leaves d(q' + pq) / d(k' + pk) per b in dnq / dnk (fp32 [B][L][H][mp])
+    const float *pq, *pk;
+    float *dnq, *dnk;
     int B, H, L, dh, m, mp, dhp;
     int kind;
     float ratio, eps, diag_c;
@@ -245,8 +249,10 @@ __global__ __launch_bounds__(256) void favor_kv_kernel(const FavorParams p) {
                 for (int kb = 0; kb < DKB; ++kb) s = mma(xf[kb], wf[mt][kb], s);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool ok = (l0 + 16 * u + 4 * g + r < L) && (mc0 + 16 * mt + li < m);
-                    const float v = ok ? feat(p.kind, s[r], dg[r] * p.diag_c, stab, p.ratio, p.eps) : 0.f;
+                    const int lt = l0 + 16 * u + 4 * g + r;
+                    const bool ok = (lt < L) && (mc0 + 16 * mt + li < m);
+                    float v = ok ? feat(p.kind, s[r], dg[r] * p.diag_c, stab, p.ratio, p.eps) : 0.f;
+                    if (p.pk && ok) v += p.pk[((long)lt * p.H + h) * p.mp + mc0 + 16 * mt + li];
                     kp[u][mt][r] = v;
                     ks[mt] += v;
                 }
@@ -323,13 +329,16 @@ __global__ __launch_bounds__(256) void favor_out_kernel(const FavorParams p) {
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float den = 0.f;
+    const float* PQ = (p.pq && l < L) ? p.pq + ((long)l * p.H + h) * p.mp : nullptr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const f32x4 ksv = *reinterpret_cast<const f32x4*>(KS + 16 * mt + 4 * g);
+        f32x4 pqv = {0.f, 0.f, 0.f, 0.f};
+        if (PQ) pqv = *reinterpret_cast<const f32x4*>(PQ + 16 * mt + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool ok = 16 * mt + 4 * g + r < m;
-            const float v = ok ? feat(p.kind, dd[mt][r], diag, mx, p.ratio, p.eps) : 0.f;
+            const float v = ok ? feat(p.kind, dd[mt][r], diag, mx, p.ratio, p.eps) + pqv[r] : 0.f;
             dd[mt][r] = v;
             den += v * ksv[r];
         }
@@ -426,13 +435,16 @@ __global__ __launch_bounds__(256) void favor_bwd_q_kernel(const FavorParams p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float den = 0.f;
         f32x4 qp[MT];
+        const float* PQ = (p.pq && l < L) ? p.pq + ((long)l * p.H + h) * p.mp : nullptr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 ksv = *reinterpret_cast<const f32x4*>(KS + 16 * mt + 4 * g);
+            f32x4 pqv = {0.f, 0.f, 0.f, 0.f};
+            if (PQ) pqv = *reinterpret_cast<const f32x4*>(PQ + 16 * mt + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = 16 * mt + 4 * g + r < m;
-                qp[mt][r] = ok ? feat(p.kind, dd[mt][r], diag, mx, p.ratio, p.eps) : 0.f;
+                qp[mt][r] = ok ? feat(p.kind, dd[mt][r], diag, mx, p.ratio, p.eps) + pqv[r] : 0.f;
                 den += qp[mt][r] * ksv[r];
             }
         }
@@ -482,13 +494,17 @@ __global__ __launch_bounds__(256) void favor_bwd_q_kernel(const FavorParams p) {
                 }
             }
             const f32x4 ksv = *reinterpret_cast<const f32x4*>(KS + 16 * mt + 4 * g);
+            f32x4 dnew;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = 16 * mt + 4 * g + r < m;
                 const float dqp = s[r] + dden * ksv[r];
+                dnew[r] = ok ? dqp : 0.f;
                 e[mt][r] = ok ? dqp * feat_grad(p.kind, dd[mt][r], diag, mx, p.ratio) : 0.f;
                 esum += e[mt][r];
             }
+            if (p.dnq && l < L)
+                *reinterpret_cast<f32x4*>(p.dnq + (((long)b * L + l) * p.H + h) * p.mp + 16 * mt + 4 * g) = dnew;
         }
         esum += __shfl_xor(esum, 16, 64);
         esum += __shfl_xor(esum, 32, 64);
@@ -540,7 +556,8 @@ __global__ __launch_bounds__(256) void favor_bwd_q_kernel(const FavorParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int lr = 4 * g + r;
                 const bool ok = (l0 + lr < L) && (16 * mt + li < m);
-                const float v = ok ? feat(p.kind, s[r], rowv[48 + lr], rowv[32 + lr], p.ratio, p.eps) : 0.f;
+                float v = ok ? feat(p.kind, s[r], rowv[48 + lr], rowv[32 + lr], p.ratio, p.eps) : 0.f;
+                if (p.pq && ok) v += p.pq[((long)(l0 + lr) * p.H + h) * p.mp + 16 * mt + li];
                 dks[mt] += v * rowv[16 + lr];
                 qn[r] = v * rowv[lr];
             }
@@ -643,13 +660,18 @@ __global__ __launch_bounds__(256) void favor_bwd_kv_kernel(const FavorParams p) 
             }
         }
         const f32x4 dksv = *reinterpret_cast<const f32x4*>(DKS + 16 * mt + 4 * g);
+        f32x4 pkv = {0.f, 0.f, 0.f, 0.f}, dnew;
+        if (p.pk && l < L) pkv = *reinterpret_cast<const f32x4*>(p.pk + ((long)l * p.H + h) * p.mp + 16 * mt + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool ok = (16 * mt + 4 * g + r < m) && (l < L);
-            kp[mt][r] = ok ? feat(p.kind, dd[mt][r], diag, stab, p.ratio, p.eps) : 0.f;
-            e[mt][r] = ok ? (s[r] + dksv[r]) * feat_grad(p.kind, dd[mt][r], diag, stab, p.ratio) : 0.f;
+            kp[mt][r] = ok ? feat(p.kind, dd[mt][r], diag, stab, p.ratio, p.eps) + pkv[r] : 0.f;
+            dnew[r] = ok ? s[r] + dksv[r] : 0.f;
+            e[mt][r] = ok ? dnew[r] * feat_grad(p.kind, dd[mt][r], diag, stab, p.ratio) : 0.f;
             esum += e[mt][r];
         }
+        if (p.dnk && l < L)
+            *reinterpret_cast<f32x4*>(p.dnk + (((long)b * L + l) * p.H + h) * p.mp + 16 * mt + 4 * g) = dnew;
     }
     float esum_l = esum;
     esum_l += __shfl_xor(esum_l, 16, 64);
@@ -701,6 +723,127 @@ __global__ void favor_fix_kernel(const FavorParams p) {
     T* DK = reinterpret_cast<T*>(p.dk) + bl * p.ld_d + h * p.dh;
     for (int d = threadIdx.x; d < p.dh; d += blockDim.x)
         DK[d] = from_f32<T>(to_f32<T>(DK[d]) - s * to_f32<T>(W[(long)mi * p.dh + d]));
+}
+
+// ------------------------------------------------------------------ position feature tables
+// The feature map on its own, applied to the [L, H*dh] projections of pos_embed (one "batch"):
+// P[l][h][.] fp32 with pitch mp (DisentangledSelfAttentionPerformer.disentangled_attention_perf_bias,
+// disentangled_transformer.py:612-644).  One wave per (l, h); lane j owns features j, j+64, ...
+// L*H*m elements in all: plain FMAs.
+constexpr int POS_MJ = 4;   // 256 features / 64 lanes
+
+template <typename T>
+__device__ __forceinline__ void pos_dd(float (&dd)[POS_MJ], float& rsum, const T* __restrict__ x, const T* __restrict__ W,
+                                       int dh, int m, int lane) {
+    rsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < POS_MJ; ++j) dd[j] = 0.f;
+    for (int d = 0; d < dh; ++d) {
+        const float xv = to_f32<T>(x[d]);
+        rsum += xv;
+#pragma unroll
+        for (int j = 0; j < POS_MJ; ++j) {
+            const int mi = lane + 64 * j;
+            if (mi < m) dd[j] += xv * to_f32<T>(W[(long)mi * dh + d]);
+        }
+    }
+}
+
+// row max of the valid dd (query stabiliser) or the stored global max (key stabiliser)
+__device__ __forceinline__ float pos_stab(const FavorParams& p, const float (&dd)[POS_MJ], int is_query, int lane) {
+    if (p.kind != FAVOR_SOFTMAX) return 0.f;
+    if (!is_query) return unordered_bits((unsigned int)(*p.kmax >> 32));
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < POS_MJ; ++j)
+        if (lane + 64 * j < p.m) mx = fmaxf(mx, dd[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    return mx;
+}
+
+// pass 0: global max (+ argmax) of the key-side dd into p.kmax;  pass 1: the features
+template <typename T>
+__global__ __launch_bounds__(64) void favor_pos_fwd_kernel(const FavorParams p, int is_query, int pass, float* feat_out) {
+    const int lane = threadIdx.x, h = blockIdx.x, l = blockIdx.y;
+    const T* x = reinterpret_cast<const T*>(p.q) + (long)l * p.ld + h * p.dh;
+    float dd[POS_MJ], rsum;
+    pos_dd<T>(dd, rsum, x, reinterpret_cast<const T*>(p.w), p.dh, p.m, lane);
+    if (pass == 0) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int j = 0; j < POS_MJ; ++j) {
+            const int mi = lane + 64 * j;
+            if (mi < p.m) {
+                const unsigned long long idx = ((unsigned long long)l * p.H + h) * p.m + mi;
+                const unsigned long long key = ((unsigned long long)ordered_bits(dd[j]) << 32) | (0xffffffffull - idx);
+                best = key > best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) atomicMax(p.kmax, best);
+        return;
+    }
+    const float diag = rsum * p.diag_c;
+    const float stab = pos_stab(p, dd, is_query, lane);
+    float* out = feat_out + ((long)l * p.H + h) * p.mp;
+#pragma unroll
+    for (int j = 0; j < POS_MJ; ++j) {
+        const int mi = lane + 64 * j;
+        if (mi < p.mp) out[mi] = mi < p.m ? feat(p.kind, dd[j], diag, stab, p.ratio, p.eps) : 0.f;
+    }
+}
+
+// dx[l][h][.] from G[l][h][.] = sum_b dfeat[b][l][h][.]; the key side's global-max term is applied by favor_fix
+template <typename T>
+__global__ __launch_bounds__(64) void favor_pos_bwd_kernel(const FavorParams p, int is_query, const float* __restrict__ dfeat,
+                                                           int nsum) {
+    __shared__ float es[64 * POS_MJ];
+    const int lane = threadIdx.x, h = blockIdx.x, l = blockIdx.y;
+    const T* x = reinterpret_cast<const T*>(p.q) + (long)l * p.ld + h * p.dh;
+    const T* W = reinterpret_cast<const T*>(p.w);
+    float dd[POS_MJ], rsum;
+    pos_dd<T>(dd, rsum, x, W, p.dh, p.m, lane);
+    const float diag = rsum * p.diag_c;
+    const float stab = pos_stab(p, dd, is_query, lane);
+    float e[POS_MJ];
+    float esum = 0.f;
+#pragma unroll
+    for (int j = 0; j < POS_MJ; ++j) {
+        const int mi = lane + 64 * j;
+        e[j] = 0.f;
+        if (mi < p.m) {
+            float gs = 0.f;
+            for (int b = 0; b < nsum; ++b) gs += dfeat[(((long)b * p.L + l) * p.H + h) * p.mp + mi];
+            e[j] = gs * feat_grad(p.kind, dd[j], diag, stab, p.ratio);
+            esum += e[j];
+        }
+    }
+    esum = wave_sum(esum);
+    float ddiag = 0.f;
+    if (p.kind == FAVOR_SOFTMAX) {
+        ddiag = -esum * p.diag_c;
+        if (is_query) {
+#pragma unroll
+            for (int j = 0; j < POS_MJ; ++j)
+                if (lane + 64 * j < p.m && dd[j] == stab) e[j] -= esum;
+        } else if (lane == 0) {
+            atomicAdd(p.esum, esum);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < POS_MJ; ++j) es[lane + 64 * j] = e[j];
+    __syncthreads();
+    T* DX = reinterpret_cast<T*>(p.dk) + (long)l * p.ld_d + h * p.dh;
+    for (int d = lane; d < p.dh; d += 64) {
+        float sacc = ddiag;
+        for (int mi = 0; mi < p.m; ++mi) sacc += es[mi] * to_f32<T>(W[(long)mi * p.dh + d]);
+        DX[d] = from_f32<T>(sacc);
+    }
 }
 
 }  // namespace vitk
@@ -824,10 +967,11 @@ static int favor_setup(FavorParams& p, int dtype, int kind, int B, int H, int L,
 
 // out = FAVOR+ attention(q, k, v; w).  kind 0 = softmax kernel, 1 = relu kernel; ratio / eps as the
 // reference computes them (m^-1/4 or m^-1/2; 1e-6 or 1e-3).  w: [m][dh] in T, contiguous.
-extern "C" int vitk_favor_fwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
-                              const void* v, long ld, const void* w, float ratio, float eps, void* out, long ldo,
-                              void* workspace, hipStream_t stream) {
+static int favor_fwd_impl(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                          const void* v, long ld, const void* w, float ratio, float eps, const float* pq, const float* pk,
+                          void* out, long ldo, void* workspace, hipStream_t stream) {
     FAVOR_COMMON_CHECKS("vitk_favor_fwd");
+    VITK_CHECK_ARG((!pq || f16al(pq)) && (!pk || f16al(pk)), "vitk_favor_fwd: position tables must be 16-byte aligned");
     const long esz = dtype == VITK_BF16 ? 2 : 4;
     VITK_CHECK_ARG(q && k && v && w && out, "vitk_favor_fwd: null pointer");
     VITK_CHECK_ARG(f16al(q) && f16al(k) && f16al(v) && f16al(out) && f16al(w) && (ld * esz) % 16 == 0 &&
@@ -836,16 +980,36 @@ extern "C" int vitk_favor_fwd(int dtype, int kind, int B, int H, int L, int dh, 
     FavorParams p = {};
     favor_setup(p, dtype, kind, B, H, L, dh, m, ratio, eps, workspace);
     p.q = q; p.k = k; p.v = v; p.ld = ld; p.w = w; p.out = out; p.ldo = ldo;
+    p.pq = pq; p.pk = pk;
     dispatch(p, dtype, false, stream);
     VITK_CHECK_LAUNCH("vitk_favor_fwd");
     return VITK_OK;
 }
 
-extern "C" int vitk_favor_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
-                              const void* v, long ld, const void* w, float ratio, float eps, const void* out,
-                              const void* dout, long ldo, void* dq, void* dk, void* dv, long ld_d, void* workspace,
-                              hipStream_t stream) {
+extern "C" int vitk_favor_fwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                              const void* v, long ld, const void* w, float ratio, float eps, void* out, long ldo,
+                              void* workspace, hipStream_t stream) {
+    return favor_fwd_impl(dtype, kind, B, H, L, dh, m, q, k, v, ld, w, ratio, eps, nullptr, nullptr, out, ldo, workspace,
+                          stream);
+}
+
+// FAVOR+ attention with position features added to both feature maps (q' + pq, k' + pk): pq / pk are fp32
+// [L][H][mp] tables made by vitk_favor_pos_fwd, mp = vitk_favor_feature_pitch(m).
+extern "C" int vitk_favor_pos_attn_fwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q,
+                                       const void* k, const void* v, long ld, const void* w, float ratio, float eps,
+                                       const float* pq, const float* pk, void* out, long ldo, void* workspace,
+                                       hipStream_t stream) {
+    VITK_CHECK_ARG(pq && pk, "vitk_favor_pos_attn_fwd: null position table");
+    return favor_fwd_impl(dtype, kind, B, H, L, dh, m, q, k, v, ld, w, ratio, eps, pq, pk, out, ldo, workspace, stream);
+}
+
+static int favor_bwd_impl(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                          const void* v, long ld, const void* w, float ratio, float eps, const float* pq, const float* pk,
+                          const void* out, const void* dout, long ldo, void* dq, void* dk, void* dv, long ld_d, float* dnq,
+                          float* dnk, void* workspace, hipStream_t stream) {
     FAVOR_COMMON_CHECKS("vitk_favor_bwd");
+    VITK_CHECK_ARG((!pq || f16al(pq)) && (!pk || f16al(pk)) && (!dnq || f16al(dnq)) && (!dnk || f16al(dnk)),
+                   "vitk_favor_bwd: position tables / gradients must be 16-byte aligned");
     const long esz = dtype == VITK_BF16 ? 2 : 4;
     VITK_CHECK_ARG(q && k && v && w && out && dout && dq && dk && dv, "vitk_favor_bwd: null pointer");
     VITK_CHECK_ARG(f16al(q) && f16al(k) && f16al(v) && f16al(out) && f16al(dout) && f16al(w) && f16al(dq) && f16al(dk) &&
@@ -857,7 +1021,102 @@ extern "C" int vitk_favor_bwd(int dtype, int kind, int B, int H, int L, int dh, 
     p.q = q; p.k = k; p.v = v; p.ld = ld; p.w = w;
     p.out = const_cast<void*>(out); p.dout = dout; p.ldo = ldo;
     p.dq = dq; p.dk = dk; p.dv = dv; p.ld_d = ld_d;
+    p.pq = pq; p.pk = pk; p.dnq = dnq; p.dnk = dnk;
     dispatch(p, dtype, true, stream);
     VITK_CHECK_LAUNCH("vitk_favor_bwd");
+    return VITK_OK;
+}
+
+extern "C" int vitk_favor_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q, const void* k,
+                              const void* v, long ld, const void* w, float ratio, float eps, const void* out,
+                              const void* dout, long ldo, void* dq, void* dk, void* dv, long ld_d, void* workspace,
+                              hipStream_t stream) {
+    return favor_bwd_impl(dtype, kind, B, H, L, dh, m, q, k, v, ld, w, ratio, eps, nullptr, nullptr, out, dout, ldo, dq,
+                          dk, dv, ld_d, nullptr, nullptr, workspace, stream);
+}
+
+// Backward of vitk_favor_pos_attn_fwd.  dnq / dnk (fp32 [B][L][H][mp], fully written) receive the gradient of the
+// summed features per batch element; vitk_favor_pos_bwd reduces them over b and goes back through the tables.
+extern "C" int vitk_favor_pos_attn_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, const void* q,
+                                       const void* k, const void* v, long ld, const void* w, float ratio, float eps,
+                                       const float* pq, const float* pk, const void* out, const void* dout, long ldo,
+                                       void* dq, void* dk, void* dv, long ld_d, float* dnq, float* dnk, void* workspace,
+                                       hipStream_t stream) {
+    VITK_CHECK_ARG(pq && pk && dnq && dnk, "vitk_favor_pos_attn_bwd: null position table / gradient");
+    return favor_bwd_impl(dtype, kind, B, H, L, dh, m, q, k, v, ld, w, ratio, eps, pq, pk, out, dout, ldo, dq, dk, dv,
+                          ld_d, dnq, dnk, workspace, stream);
+}
+
+// Row pitch (floats) of the position-feature tables and of dnq / dnk for m random features.
+extern "C" int vitk_favor_feature_pitch(int m) { return 16 * pick_mt(m); }
+
+#define FAVOR_POS_CHECKS(name)                                                                                     \
+    VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, name ": bad dtype");                                   \
+    VITK_CHECK_ARG(kind == FAVOR_SOFTMAX || kind == FAVOR_RELU, name ": kernel must be 0 (softmax) or 1 (relu)");  \
+    VITK_CHECK_ARG(H > 0 && L > 0 && H <= 65535 && L <= 65535, name ": empty or oversized problem");               \
+    VITK_CHECK_ARG(dh > 0 && dh <= 64, name ": head dim %d unsupported", dh);                                      \
+    VITK_CHECK_ARG(m > 0 && m <= 256, name ": 1..256 random features supported, got %d", m);                       \
+    VITK_CHECK_ARG(x && w && state && f16al(state) && ld >= (long)H * dh, name ": bad x / w / state")
+
+static void favor_pos_params(FavorParams& p, int kind, int H, int L, int dh, int m, const void* x, long ld, const void* w,
+                             float ratio, float eps, void* state) {
+    p.q = x; p.ld = ld; p.w = w;
+    p.kmax = reinterpret_cast<unsigned long long*>(state);
+    p.esum = reinterpret_cast<float*>(reinterpret_cast<char*>(state) + 8);
+    p.B = 1; p.H = H; p.L = L; p.dh = dh; p.m = m; p.mp = 16 * pick_mt(m);
+    p.kind = kind; p.ratio = ratio; p.eps = eps;
+    p.diag_c = 0.5f / sqrtf((float)dh);
+}
+
+// Position-feature table: feat[l][h][.] = feature map (query form: row max; key form: max over the whole
+// [L][H][m] tensor) of x[l][h*dh ..], x = pos_query_proj / pos_key_proj of pos_embed ([L, >= H*dh] in T).
+// Replaces softmax_kernel_transformation / relu_kernel_transformation as called at
+// disentangled_transformer.py:623-641.  state: 16 bytes (256-byte buffer recommended) that keep the key
+// max / argmax for vitk_favor_pos_bwd.
+extern "C" int vitk_favor_pos_fwd(int dtype, int kind, int is_query, int H, int L, int dh, int m, const void* x, long ld,
+                                  const void* w, float ratio, float eps, float* feat_out, void* state,
+                                  hipStream_t stream) {
+    FAVOR_POS_CHECKS("vitk_favor_pos_fwd");
+    VITK_CHECK_ARG(feat_out && f16al(feat_out), "vitk_favor_pos_fwd: feat must be 16-byte aligned");
+    FavorParams p = {};
+    favor_pos_params(p, kind, H, L, dh, m, x, ld, w, ratio, eps, state);
+    const dim3 grid(H, L);
+    if (dtype == VITK_BF16) {
+        if (kind == FAVOR_SOFTMAX && !is_query) {
+            (void)vitk_zero_async(state, 16, 16, 1, stream);
+            hipLaunchKernelGGL(favor_pos_fwd_kernel<__bf16>, grid, dim3(64), 0, stream, p, is_query, 0, feat_out);
+        }
+        hipLaunchKernelGGL(favor_pos_fwd_kernel<__bf16>, grid, dim3(64), 0, stream, p, is_query, 1, feat_out);
+    } else {
+        if (kind == FAVOR_SOFTMAX && !is_query) {
+            (void)vitk_zero_async(state, 16, 16, 1, stream);
+            hipLaunchKernelGGL(favor_pos_fwd_kernel<float>, grid, dim3(64), 0, stream, p, is_query, 0, feat_out);
+        }
+        hipLaunchKernelGGL(favor_pos_fwd_kernel<float>, grid, dim3(64), 0, stream, p, is_query, 1, feat_out);
+    }
+    VITK_CHECK_LAUNCH("vitk_favor_pos_fwd");
+    return VITK_OK;
+}
+
+// dx[l][h*dh ..] (T, [L, ld_d]) from dfeat (fp32 [nsum][L][H][mp], summed over its first dim here).
+extern "C" int vitk_favor_pos_bwd(int dtype, int kind, int is_query, int nsum, int H, int L, int dh, int m, const void* x,
+                                  long ld, const void* w, float ratio, float eps, const float* dfeat, void* dx, long ld_d,
+                                  void* state, hipStream_t stream) {
+    FAVOR_POS_CHECKS("vitk_favor_pos_bwd");
+    VITK_CHECK_ARG(nsum > 0 && dfeat && dx && ld_d >= (long)H * dh, "vitk_favor_pos_bwd: bad dfeat / dx");
+    FavorParams p = {};
+    favor_pos_params(p, kind, H, L, dh, m, x, ld, w, ratio, eps, state);
+    p.dk = dx; p.ld_d = ld_d;
+    const bool fix = kind == FAVOR_SOFTMAX && !is_query;
+    if (fix) (void)vitk_zero_async(p.esum, 4, 4, 1, stream);
+    const dim3 grid(H, L);
+    if (dtype == VITK_BF16) {
+        hipLaunchKernelGGL(favor_pos_bwd_kernel<__bf16>, grid, dim3(64), 0, stream, p, is_query, dfeat, nsum);
+        if (fix) hipLaunchKernelGGL(favor_fix_kernel<__bf16>, dim3(1), dim3(64), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(favor_pos_bwd_kernel<float>, grid, dim3(64), 0, stream, p, is_query, dfeat, nsum);
+        if (fix) hipLaunchKernelGGL(favor_fix_kernel<float>, dim3(1), dim3(64), 0, stream, p);
+    }
+    VITK_CHECK_LAUNCH("vitk_favor_pos_bwd");
     return VITK_OK;
 }

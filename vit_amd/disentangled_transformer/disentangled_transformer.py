@@ -3,7 +3,7 @@
 Class names, constructor / forward signatures and state_dict keys follow
 ``disentangled_transformer/disentangled_transformer.py`` in the reference
 (DisentangledTransformer :15, DisentangledEncoder :75, DisentangledEncoderLayer :130,
-DisentangledSelfAttention :248, DisentangledLAISelfAttention :788).  Parameters the reference
+DisentangledSelfAttention :248, DisentangledSelfAttentionPerformer :431, DisentangledLAISelfAttention :788).  Parameters the reference
 allocates but never uses (pos_key_proj / pos_query_proj, the layer-level query/key/value_proj)
 are kept so checkpoints load; they receive no gradient here either.
 
@@ -23,6 +23,7 @@ import torch.nn as nn
 from .. import functional as VF
 from ..precision import ComputeDtypeMixin
 from ..timm_classes.timm_locality_aware_transformer import _check_p0, get_attn_mask, lai_stage_width  # noqa: F401
+from ..timm_classes.timm_vision_performer import gaussian_orthogonal_random_matrix, orthogonal_matrix_chunk
 
 _band_idx_cache = {}
 
@@ -128,11 +129,82 @@ class DisentangledLAISelfAttention(DisentangledSelfAttention):
         self.mask_epochs = mask_epochs
 
 
-class DisentangledSelfAttentionPerformer(nn.Module):
-    def __init__(self, *args, **kwargs):
+class DisentangledSelfAttentionPerformer(ComputeDtypeMixin, nn.Module):
+    """FAVOR+ with position features (reference :431-785).  What the reference's live
+    code computes (:586-602): new_Q = q' + Pq, new_K = k' + Pk, linear attention over them, where
+    q' / k' are the random-feature maps of the content projections and Pq / Pk those of
+    pos_query_proj / pos_key_proj(pos_embed) (:612-644) -- one [N, H, m] table each, shared by the
+    batch.  The feature maps are the class's own (:717-749), quirks kept: projection unscaled, diag
+    from the plain sum, key stabiliser = max over the whole tensor, ratio m^-1/4 for both kernels.
+    ``w`` ([m, dh], drawn on first use, not in the state_dict) as upstream."""
+
+    def __init__(self, d_model=512, nhead=8, dropout=0.1, relative_attention=False, pos_att_type='c2p|p2c',
+                 position_buckets=-1, max_relative_positions=-1, max_position_embeddings=512, norf=32,
+                 kernel='softmax'):
         super().__init__()
-        raise NotImplementedError('DisentangledSelfAttentionPerformer (reference :431-785) is marked unfinished '
-                                  'upstream and is outside this build (SURVEY.md 8f, item 1)')
+        self.m = int(norf)
+        self.w = None
+        self.kernel = kernel
+        self.num_attention_heads = nhead
+        self.attention_head_size = self.head_dim = int(d_model / nhead)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.pos_att_type = [x.strip() for x in pos_att_type.lower().split('|')]
+        self.relative_attention = relative_attention
+        self.share_att_key = True
+        if kernel not in ('softmax', 'relu'):
+            raise ValueError(f'unknown FAVOR+ kernel {kernel!r}')
+        if not relative_attention or 'c2p' not in self.pos_att_type or 'p2c' not in self.pos_att_type:
+            # the reference leaves Pq / Pk undefined in these cases (:621-644) and fails at :587
+            raise NotImplementedError("DisentangledSelfAttentionPerformer needs relative_attention=True and "
+                                      "pos_att_type with both 'c2p' and 'p2c' (the reference's only working form)")
+        self.query_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.key_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.value_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.position_buckets = position_buckets
+        self.max_relative_positions = max_relative_positions
+        if self.max_relative_positions < 1:
+            self.max_relative_positions = max_position_embeddings
+        self.pos_ebd_size = self.max_relative_positions
+        if self.position_buckets > 0:
+            self.pos_ebd_size = self.position_buckets
+        self.pos_dropout = nn.Dropout(dropout)
+        self.pos_key_proj = nn.Linear(d_model, self.all_head_size, bias=True)
+        self.pos_query_proj = nn.Linear(d_model, self.all_head_size)
+        self.dropout = nn.Dropout(dropout)
+        self.mask_epochs = None
+
+    gaussian_orthogonal_random_matrix = staticmethod(gaussian_orthogonal_random_matrix)
+    orthogonal_matrix_chunk = staticmethod(orthogonal_matrix_chunk)
+
+    def ratio(self):
+        return 1.0 / math.sqrt(math.sqrt(self.m))           # reference :720,744
+
+    def attend2d(self, x2, pos2, B, N):
+        """x2 [B*N, D], pos2 [N, D] (pos_embed rows), compute dtype -> context [B*N, D]."""
+        _check_p0(self, self.dropout.p)
+        if pos2 is None:
+            raise ValueError('DisentangledSelfAttentionPerformer needs pos_embed (reference :614)')
+        if pos2.shape != (N, x2.shape[1]):
+            raise ValueError(f'pos_embed has {tuple(pos2.shape)} rows x cols, the sequence needs {(N, x2.shape[1])}')
+        if self.w is None:
+            self.w = gaussian_orthogonal_random_matrix(self.m, self.head_dim, device=x2.device)
+        qkv = VF.fused_linear(x2, self.query_proj, self.key_proj, self.value_proj)
+        posqk = VF.fused_linear(pos2, self.pos_query_proj, self.pos_key_proj)
+        return VF.favor_pos_attention(qkv, posqk, self.w.to(x2.device), B, N, self.num_attention_heads,
+                                      self.attention_head_size, self.kernel, self.ratio())
+
+    def forward(self, q, k, value, relative_pos=None, rel_embeddings=None, query=None, pos_embed=None):
+        """pos_embed: [N, 1, D] as the encoder hands it down (reference :69,614).  relative_pos /
+        rel_embeddings are accepted and unused, as upstream (:614 overwrites them)."""
+        if query is not None:
+            q = query
+        if not (q is k and k is value):
+            raise NotImplementedError('cross attention is not on the reference hot path (q = k = value = src, :210)')
+        B, N, D = q.shape
+        dt = self.compute_dtype
+        pos2 = None if pos_embed is None else pos_embed.reshape(-1, D).to(dt)
+        ctx = self.attend2d(q.reshape(B * N, D).to(dt), pos2, B, N)
+        return {'hidden_states': ctx.view(B, N, D).to(q.dtype), 'attention_probs': None, 'attention_logits': None}
 
 
 class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
@@ -143,6 +215,7 @@ class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
         kw = dict(d_model=d_model, nhead=nhead, dropout=dropout, relative_attention=relative_attention,
                   pos_att_type=pos_att_type, position_buckets=position_buckets,
                   max_relative_positions=max_relative_positions, max_position_embeddings=max_position_embeddings)
+        self.performers = bool(performers)
         if performers:
             self.dis_attn = DisentangledSelfAttentionPerformer(kernel=kernel, norf=norf, **kw)
         elif lai:
@@ -165,6 +238,19 @@ class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
         self.dense_out = nn.Linear(dim_feedforward, d_model)
         self.layer_norm_out = nn.LayerNorm(d_model)
         self.dropout_out = nn.Dropout(dropout)
+
+    def forward2d_performer(self, x2, pos2, B, N):
+        """The layer with FAVOR+ attention (reference :200-246 with dis_attn = the Performer variant): post-LN,
+        residuals in the GEMM epilogues."""
+        a = self.dis_attn
+        _check_p0(self, self.dropout_AttnOut.p, self.dropout_out.p)
+        ctx = a.attend2d(x2, pos2, B, N)
+        n1, n2 = self.layer_norm_AttnOut, self.layer_norm_out
+        h = VF.layer_norm(VF.linear_res(ctx, self.dense_AttnOut.weight, self.dense_AttnOut.bias, x2),
+                          n1.weight, n1.bias, n1.eps)
+        y = VF.mlp(h, self.dense_intermediate.weight, self.dense_intermediate.bias, self.dense_out.weight,
+                   self.dense_out.bias, 'gelu', add_input=True)
+        return VF.layer_norm(y, n2.weight, n2.bias, n2.eps)
 
     def forward2d(self, x2, band, B, N, epoch, x_ext=False):
         """x2 [B*N, D] and band [2N-1, D] (or None) in compute dtype -> [B*N, D]; one autograd node.
@@ -189,6 +275,12 @@ class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
             raise NotImplementedError('query != src is not on the reference hot path')
         B, N, D = src.shape
         dt = self.compute_dtype
+        if self.performers:
+            if epoch is not None:       # the reference passes it on (:218-220) to a forward() that has no such argument
+                raise TypeError("DisentangledSelfAttentionPerformer.forward() got an unexpected keyword argument 'epoch'")
+            pos2 = None if pos_embed is None else pos_embed.reshape(-1, D).to(dt)
+            y = self.forward2d_performer(src.reshape(B * N, D).to(dt), pos2, B, N)
+            return y.view(B, N, D).to(src.dtype)
         band = self.dis_attn.band_for(rel_embeddings, N, dt)
         y = self.forward2d(src.reshape(B * N, D).to(dt), band, B, N, epoch)
         return y.view(B, N, D).to(src.dtype)
@@ -205,6 +297,7 @@ class DisentangledEncoder(ComputeDtypeMixin, nn.Module):
         self.layers = _get_clones(encoder_layer, num_layers)
         self.num_layers = num_layers
         self.norm = norm
+        self.performers = bool(performers)
         d_model = encoder_layer.embed_size
         max_position_embeddings = d_model   # as the reference (:87)
         self.relative_attention = relative_attention
@@ -226,10 +319,19 @@ class DisentangledEncoder(ComputeDtypeMixin, nn.Module):
             return None
         return VF.layer_norm(self.rel_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
 
-    def encode2d(self, x2, B, N, epoch):
-        """Layers only (no final norm) on a 2-D token matrix in compute dtype."""
-        rel = self.get_rel_embedding()
+    def encode2d(self, x2, B, N, epoch, pos_embed=None):
+        """Layers only (no final norm) on a 2-D token matrix in compute dtype.  ``pos_embed`` ([1, N, D] or
+        [N, 1, D]): read by the Performer variant only (reference :124,614)."""
         dt = self.compute_dtype
+        if self.performers:
+            if epoch is not None:
+                raise TypeError("DisentangledSelfAttentionPerformer.forward() got an unexpected keyword argument 'epoch'")
+            # the relative table and its LayerNorm (:117-118) are computed and discarded upstream: not run here
+            pos2 = None if pos_embed is None else pos_embed.reshape(-1, x2.shape[1]).to(dt)
+            for layer in self.layers:
+                x2 = layer.forward2d_performer(x2, pos2, B, N)
+            return x2
+        rel = self.get_rel_embedding()
         band = None
         for i, layer in enumerate(self.layers):
             if band is None:
@@ -240,7 +342,7 @@ class DisentangledEncoder(ComputeDtypeMixin, nn.Module):
     def forward(self, src, pos=None, epoch=None):
         B, N, D = src.shape
         dt = self.compute_dtype
-        x2 = self.encode2d(src.reshape(B * N, D).to(dt), B, N, epoch)
+        x2 = self.encode2d(src.reshape(B * N, D).to(dt), B, N, epoch, pos_embed=pos)
         if self.norm is not None:
             x2 = VF.layer_norm(x2, self.norm.weight, self.norm.bias, self.norm.eps)
         return x2.view(B, N, D).to(src.dtype)
@@ -270,15 +372,20 @@ class DisentangledTransformer(ComputeDtypeMixin, nn.Module):
                 nn.init.xavier_uniform_(p)
 
     # protocol used by vit_amd.model.VisionTransformer's fused path
-    def encode2d(self, x2, B, N, epoch):
-        return self.encoder.encode2d(x2, B, N, epoch)
+    def encode2d(self, x2, B, N, epoch, pos_embed=None):
+        return self.encoder.encode2d(x2, B, N, epoch, pos_embed=pos_embed)
+
+    @property
+    def uses_pos_embed(self):
+        return self.encoder.performers
 
     @property
     def final_norm(self):
         return self.encoder.norm
 
     def forward(self, src, pos_embed, epoch=None):
-        """[B,N,D] -> [N,B,D]; ``pos_embed`` is accepted and, as in the reference (:121 commented
-        out), never added."""
-        memory = self.encoder(src, pos=None, epoch=epoch)
+        """[B,N,D] -> [N,B,D]; ``pos_embed`` ([1,N,D]) is, as in the reference (:121 commented out), never
+        added to the tokens; only the Performer variant reads it (:614)."""
+        pos = pos_embed.permute(1, 0, 2) if (self.encoder.performers and pos_embed is not None) else None
+        memory = self.encoder(src, pos=pos, epoch=epoch)
         return memory.permute(1, 0, 2)

@@ -219,6 +219,57 @@ def linear(x2d, weight, bias=None, out_dtype=None):
     return LinearFn.apply(x2d, weight, bias, out_dtype)
 
 
+class FusedLinearFn(torch.autograd.Function):
+    """y = x [W_1; ..; W_k]^T + [b_1; ..; b_k]: several nn.Linear over the same rows as one GEMM
+    (one cached copy of the stacked weights: shadow)."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        ctx.save_for_backward(x, *ws)
+        return ops.gemm(x, shadow(tuple(ws), x.dtype), bias=torch.cat([b.detach() for b in bs]))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *ws = ctx.saved_tensors
+        dy = dy.to(x.dtype).contiguous()
+        dx = _dx(dy, tuple(ws)) if ctx.needs_input_grad[0] else None
+        dw, db = _dw(dy, x), ops.colsum(dy)
+        grads, off = [], 0
+        for w in ws:
+            n = w.shape[0]
+            grads += [dw[off:off + n], db[off:off + n]]
+            off += n
+        return (dx, *grads)
+
+
+def fused_linear(x2d, *linears):
+    """``linears``: nn.Linear modules (all with bias) applied to the same rows; outputs side by side."""
+    args = []
+    for lin in linears:
+        args += [lin.weight, lin.bias]
+    return FusedLinearFn.apply(x2d, *args)
+
+
+class LinearResFn(torch.autograd.Function):
+    """y = x W^T + b + res on 2-D rows (the residual rides in the GEMM epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res):
+        ctx.save_for_backward(x, weight)
+        return ops.gemm(x, shadow(weight, x.dtype), bias=_f32(bias), residual=res)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.to(x.dtype).contiguous()
+        return _dx(dy, weight), _dw(dy, x), ops.colsum(dy), dy
+
+
+def linear_res(x2d, weight, bias, res):
+    return LinearResFn.apply(x2d, weight, bias, res)
+
+
 # --------------------------------------------------------------------------- attention core
 def _attn_fwd(qkv, B, N, H, dh, tables, scale, w):
     """qkv [B*N, 3D] (q | k | v).  tables: None or [2N-1, 2D] (Pq | Pk)."""
@@ -590,23 +641,25 @@ class MlpFn(torch.autograd.Function):
     """act(x W1^T + b1) W2^T + b2 with the activation fused into the GEMM epilogues."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act):
+    def forward(ctx, x, w1, b1, w2, b2, act, add_input=False):
         dt = x.dtype
-        y, hmid, pre = _mlp_fwd(x, shadow(w1, dt), _f32(b1), shadow(w2, dt), _f32(b2), act, None)
+        y, hmid, pre = _mlp_fwd(x, shadow(w1, dt), _f32(b1), shadow(w2, dt), _f32(b2), act, x if add_input else None)
         ctx.save_for_backward(x, w1, w2, hmid, pre)
         ctx.act = act
+        ctx.add_input = add_input
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w1, w2, hmid, pre = ctx.saved_tensors
-        dt = x.dtype
-        dx, dw1, db1, dw2, db2 = _mlp_bwd(dy.contiguous(), x, w1, w2, ctx.act, hmid, pre, None)
-        return dx, dw1, db1, dw2, db2, None
+        dy = dy.contiguous()
+        dx, dw1, db1, dw2, db2 = _mlp_bwd(dy, x, w1, w2, ctx.act, hmid, pre, dy if ctx.add_input else None)
+        return dx, dw1, db1, dw2, db2, None, None
 
 
-def mlp(x2d, w1, b1, w2, b2, act='gelu'):
-    return MlpFn.apply(x2d, w1, b1, w2, b2, act)
+def mlp(x2d, w1, b1, w2, b2, act='gelu', add_input=False):
+    """add_input: y = mlp(x) + x (the post-LN layers' residual, fused into the fc2 epilogue)."""
+    return MlpFn.apply(x2d, w1, b1, w2, b2, act, add_input)
 
 
 # --------------------------------------------------------------------------- FAVOR+ (Performer)
@@ -636,12 +689,52 @@ class FavorAttentionFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None, None
 
 
+class FavorPosAttentionFn(torch.autograd.Function):
+    """FAVOR+ with position features (DisentangledSelfAttentionPerformer, reference dis :586-602):
+    new_Q = q' + Pq, new_K = k' + Pk with Pq / Pk the query- / key-form feature maps of ``posqk``
+    = [pos_query_proj(pos_embed) | pos_key_proj(pos_embed)]  ([L, 2D])."""
+
+    @staticmethod
+    def forward(ctx, qkv, posqk, w, B, L, H, dh, kind, ratio, eps):
+        D = H * dh
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        pq, sq = ops.favor_pos_fwd(posqk[:, :D], H, dh, w, kind, True, ratio, eps)
+        pk, sk = ops.favor_pos_fwd(posqk[:, D:], H, dh, w, kind, False, ratio, eps)
+        ws = ops.favor_workspace(qkv, B, H, dh, w.shape[0])
+        out = ops.favor_pos_attn_fwd(q, k, v, B, H, L, dh, qkv.stride(0), w, kind, ratio, eps, pq, pk, ws)
+        ctx.save_for_backward(qkv, posqk, w, out, ws, pq, pk, sq, sk)
+        ctx.cfg = (B, L, H, dh, kind, ratio, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, posqk, w, out, ws, pq, pk, sq, sk = ctx.saved_tensors
+        B, L, H, dh, kind, ratio, eps = ctx.cfg
+        D = H * dh
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        dqkv = torch.empty_like(qkv)
+        dnq, dnk = ops.favor_pos_attn_bwd(q, k, v, B, H, L, dh, qkv.stride(0), w, kind, ratio, eps, pq, pk, out,
+                                          dout.contiguous(), dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, ws)
+        dpos = torch.cat([ops.favor_pos_bwd(posqk[:, :D], H, dh, w, kind, True, ratio, eps, dnq, sq),
+                          ops.favor_pos_bwd(posqk[:, D:], H, dh, w, kind, False, ratio, eps, dnk, sk)], dim=1)
+        return dqkv, dpos, None, None, None, None, None, None, None, None
+
+
+def _favor_kind(kernel):
+    if kernel == 'softmax':
+        return ops.FAVOR_SOFTMAX, 1e-6
+    if kernel == 'relu':
+        return ops.FAVOR_RELU, 1e-3
+    raise ValueError(f'unknown FAVOR+ kernel {kernel!r}')
+
+
+def favor_pos_attention(qkv, posqk, w, B, L, H, dh, kernel, ratio):
+    """qkv [B*L, 3D], posqk [L, 2D] (position query | key projections), w [m, dh]."""
+    kind, eps = _favor_kind(kernel)
+    return FavorPosAttentionFn.apply(qkv, posqk, w.to(qkv.dtype).contiguous(), B, L, H, dh, kind, float(ratio), eps)
+
+
 def favor_attention(qkv, w, B, L, H, dh, kernel, ratio):
     """kernel: 'softmax' (eps 1e-6) or 'relu' (eps 1e-3), as the reference's two feature maps."""
-    if kernel == 'softmax':
-        kind, eps = ops.FAVOR_SOFTMAX, 1e-6
-    elif kernel == 'relu':
-        kind, eps = ops.FAVOR_RELU, 1e-3
-    else:
-        raise ValueError(f'unknown FAVOR+ kernel {kernel!r}')
+    kind, eps = _favor_kind(kernel)
     return FavorAttentionFn.apply(qkv, w.to(qkv.dtype).contiguous(), B, L, H, dh, kind, float(ratio), eps)

@@ -51,7 +51,10 @@ class VisionTransformer(ComputeDtypeMixin, nn.Module):
         tok = VF.patch_embed(img, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token, None, dt)
         tr = self.transformer
         if hasattr(tr, 'encode2d'):
-            x2 = tr.encode2d(tok, B, N, epoch)
+            if getattr(tr, 'uses_pos_embed', False):      # DisentangledSelfAttentionPerformer reads it (dis :614)
+                x2 = tr.encode2d(tok, B, N, epoch, pos_embed=self.pos_embed)
+            else:
+                x2 = tr.encode2d(tok, B, N, epoch)
             cls = x2.view(B, N, D)[:, 0]          # both trailing LayerNorms are row-wise: class rows only
             if tr.final_norm is not None:
                 cls = VF.layer_norm(cls, tr.final_norm.weight, tr.final_norm.bias, tr.final_norm.eps)

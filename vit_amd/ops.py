@@ -310,3 +310,74 @@ def favor_bwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, out, dout, dq, dk, 
                               w.data_ptr(), float(ratio), float(eps), out.data_ptr(), dout.data_ptr(), H * dh,
                               dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d, workspace.data_ptr(), _stream())
     check(st, 'vitk_favor_bwd')
+
+
+def favor_feature_pitch(m):
+    return lib().vitk_favor_feature_pitch(int(m))
+
+
+def favor_pos_fwd(x, H, dh, w, kind, is_query, ratio, eps):
+    """Position-feature table of x [L, >= H*dh] (pos_query_proj / pos_key_proj of pos_embed):
+    (feat fp32 [L, H, mp], state) -- state keeps the key max / argmax for favor_pos_bwd."""
+    _req_cuda(x, w)
+    if w.dtype != x.dtype or not w.is_contiguous() or w.shape[1] != dh or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError('favor_pos: x must be 2-D rows, w contiguous [m, dh], both in the compute dtype')
+    L, m = x.shape[0], w.shape[0]
+    feat = torch.empty(L, H, favor_feature_pitch(m), device=x.device, dtype=torch.float32)
+    state = torch.empty(64, device=x.device, dtype=torch.float32)
+    st = lib().vitk_favor_pos_fwd(_dt(x), kind, int(is_query), H, L, dh, m, x.data_ptr(), x.stride(0), w.data_ptr(),
+                                  float(ratio), float(eps), feat.data_ptr(), state.data_ptr(), _stream())
+    check(st, 'vitk_favor_pos_fwd')
+    return feat, state
+
+
+def favor_pos_bwd(x, H, dh, w, kind, is_query, ratio, eps, dfeat, state):
+    """dx [L, H*dh] from dfeat fp32 [nsum, L, H, mp] (summed over nsum in the kernel)."""
+    _req_cuda(x, w, dfeat, state)
+    L, m = x.shape[0], w.shape[0]
+    if dfeat.dtype != torch.float32 or not dfeat.is_contiguous() or \
+            tuple(dfeat.shape[1:]) != (L, H, favor_feature_pitch(m)):
+        raise ValueError('favor_pos_bwd: dfeat must be contiguous fp32 [nsum, L, H, mp]')
+    dx = torch.empty(L, H * dh, device=x.device, dtype=x.dtype)
+    st = lib().vitk_favor_pos_bwd(_dt(x), kind, int(is_query), dfeat.shape[0], H, L, dh, m, x.data_ptr(), x.stride(0),
+                                  w.data_ptr(), float(ratio), float(eps), dfeat.data_ptr(), dx.data_ptr(), H * dh,
+                                  state.data_ptr(), _stream())
+    check(st, 'vitk_favor_pos_bwd')
+    return dx
+
+
+def _check_pos_tables(L, H, m, *ts):
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape[-3:]) != (L, H, favor_feature_pitch(m)):
+            raise ValueError('favor_pos_attn: position tables / gradients must be contiguous fp32 [.., L, H, mp]')
+
+
+def favor_pos_attn_fwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, pq, pk, workspace):
+    """favor_fwd with position features: q' + pq, k' + pk (fp32 [L, H, mp] from favor_pos_fwd)."""
+    _req_cuda(q, k, v, w, pq, pk, workspace)
+    if w.dtype != q.dtype or not w.is_contiguous() or w.shape[1] != dh:
+        raise ValueError('favor: w must be contiguous [m, dh] in the compute dtype')
+    _check_pos_tables(L, H, w.shape[0], pq, pk)
+    out = torch.empty(B * L, H * dh, device=q.device, dtype=q.dtype)
+    st = lib().vitk_favor_pos_attn_fwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                       ld, w.data_ptr(), float(ratio), float(eps), pq.data_ptr(), pk.data_ptr(),
+                                       out.data_ptr(), H * dh, workspace.data_ptr(), _stream())
+    check(st, 'vitk_favor_pos_attn_fwd')
+    return out
+
+
+def favor_pos_attn_bwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, pq, pk, out, dout, dq, dk, dv, ld_d, workspace):
+    """Returns (dnq, dnk): fp32 [B, L, H, mp] gradients of the summed features, per batch element."""
+    _req_cuda(q, k, v, w, pq, pk, out, dout, dq, dk, dv, workspace)
+    if not (out.is_contiguous() and dout.is_contiguous()) or dout.shape != out.shape:
+        raise ValueError('favor_bwd: out / dout must be contiguous [B*L, H*dh]')
+    _check_pos_tables(L, H, w.shape[0], pq, pk)
+    dnq = torch.empty(B, L, H, pq.shape[-1], device=q.device, dtype=torch.float32)
+    dnk = torch.empty_like(dnq)
+    st = lib().vitk_favor_pos_attn_bwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                       ld, w.data_ptr(), float(ratio), float(eps), pq.data_ptr(), pk.data_ptr(),
+                                       out.data_ptr(), dout.data_ptr(), H * dh, dq.data_ptr(), dk.data_ptr(),
+                                       dv.data_ptr(), ld_d, dnq.data_ptr(), dnk.data_ptr(), workspace.data_ptr(),
+                                       _stream())
+    check(st, 'vitk_favor_pos_attn_bwd')
+    return dnq, dnk

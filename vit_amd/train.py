@@ -34,7 +34,7 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
                 mask_epochs=None, dtype=torch.bfloat16, device='cuda', **over):
     """Model factory for the --attention variants on the hot path (train.py:97-253):
     'transformer' (regular, pre-LN, ReLU), 'transformer_timm_lai', 'disentangled_attention',
-    'disentangled_lai_attention'.  Dropout is 0 (parity and benchmarks are defined at p = 0)."""
+    'disentangled_lai_attention', 'disentangled_performer', 'performer_timm', 'performer'.  Dropout is 0 (parity and benchmarks are defined at p = 0)."""
     p = dict(PRESETS[preset], **{k: v for k, v in over.items() if k in ('depth', 'dim', 'mlp', 'heads')})
     if attention == 'transformer':
         tr = M.Transformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
@@ -52,6 +52,14 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
                                      num_encoder_layers=p['depth'], normalize_before=True, pos_att_type='c2p|p2c',
                                      max_position_embeddings=p['dim'], relative_attention=True, lai=lai,
                                      mask_epochs=mask_epochs if lai else None)
+        net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                  num_classes=num_classes, transformer=tr)
+    elif attention == 'disentangled_performer':
+        # train.py:215-234: FAVOR+ with position features inside the DeBERTa-style post-LN layers
+        tr = DisentangledTransformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+                                     num_encoder_layers=p['depth'], normalize_before=True, pos_att_type='c2p|p2c',
+                                     max_position_embeddings=p['dim'], relative_attention=True, performers=True,
+                                     norf=over.get('num_orf', 16), kernel=over.get('kernel', 'softmax'))
         net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
                                   num_classes=num_classes, transformer=tr)
     elif attention == 'performer_timm':
@@ -76,8 +84,9 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
 
 
 def takes_epoch(net):
+    tr = getattr(net, 'transformer', None)
     return isinstance(net, VisionTransformerLAI) or \
-        isinstance(getattr(net, 'transformer', None), DisentangledTransformer)
+        (isinstance(tr, DisentangledTransformer) and not tr.uses_pos_embed)    # the Performer variant takes none
 
 
 def train_step(net, optimizer, img, target, epoch=None, smoothing=0.1, reducer=None):
