@@ -38,6 +38,7 @@ WORKLOADS = {
     'dislai_l16': ('disentangled_lai_attention', 'L', 224, 16, 1000, 64),
     'regular_cifar': ('transformer', 'cifar', 32, 4, 10, 128),
     'performer_s16_384': ('performer_timm', 'S', 384, 16, 1000, 64),      # config 5, FAVOR+ m = 64 (GPU line only)
+    'disperf_s16': ('disentangled_performer', 'S', 224, 16, 1000, 128),   # SURVEY 8(f)-1, m = 16 (train.py:75; GPU line only)
 }
 MASK_EPOCHS = [10, 20, 30, 40]
 STAGE_EPOCH = {8: 0, 12: 10, 18: 20, 20: 30, -1: 40}
@@ -50,12 +51,13 @@ def train_flops_per_image(variant, p, N, P, C, B, w):
     fwd = 2.0 * (N - 1) * 3 * P * P * D + 2.0 * D * C
     wbar = N if w < 0 else (N * (2 * w + 1) - w * (w + 1)) / N
     lin = 8.0 * N * D * D + 4.0 * N * D * F
-    if variant.startswith('disentangled'):
+    if 'performer' in variant:
+        m = 16 if variant == 'disentangled_performer' else 64
+        attn = 8.0 * N * D * m + 2.0 * N * m * H          # FAVOR+ with m random features
+        table = 4.0 * N * D * D / B if variant == 'disentangled_performer' else 0.0    # pos_query / pos_key projections
+    elif variant.startswith('disentangled'):
         attn = 8.0 * N * wbar * D
         table = 4.0 * (2 * N - 1) * D * D / B
-    elif variant.startswith('performer'):
-        attn = 8.0 * N * D * 64 + 2.0 * N * 64 * H        # FAVOR+ with m = 64 random features
-        table = 0.0
     else:
         attn = 4.0 * N * wbar * D
         table = 0.0
@@ -232,7 +234,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and not variant.startswith('performer'):   # no oracle model of config 5's shell
+        if world == 1 and not args.no_cpu_baseline and 'performer' not in variant:   # no oracle model of the FAVOR+ models' shells
             cpu = cpu_baseline(args, variant, preset, img, patch, classes, w)
         out = {
             'metric': 'train images/sec (node) ViT-B/16-224 LAI+Dis' if args.workload == 'dislai_b16'

@@ -157,13 +157,14 @@ int vitk_favor_bwd(int dtype, int kind, int B, int H, int L, int dh, int m, cons
  * table each, the same for every batch element.
  * vitk_favor_feature_pitch(m): row pitch mp (floats) of every table below.
  * vitk_favor_pos_fwd: x [L, ld] (T) -> feat fp32 [L][H][mp]; is_query picks the row max (:732) or the
- *   max over the whole table (:736) as stabiliser; `state` (>= 16 bytes, 16-byte aligned) keeps the key
- *   max / argmax for the backward.
+ *   max over the whole table (:736) as stabiliser; `state` (vitk_favor_pos_state_bytes(H, L) bytes, 16-byte
+ *   aligned) keeps the key max / argmax for the backward, which also parks partial sums there.
  * vitk_favor_pos_attn_fwd / _bwd: vitk_favor_fwd / _bwd with the tables added; the backward also fills
  *   dnq / dnk (fp32 [B][L][H][mp]) with d loss / d new_Q and d new_K per batch element.
  * vitk_favor_pos_bwd: sums dfeat over its first dim (nsum = B) and goes back through the feature map,
  *   both maxima included: dx [L, ld_d] (T). */
 int vitk_favor_feature_pitch(int m);
+long vitk_favor_pos_state_bytes(int H, int L);
 int vitk_favor_pos_fwd(int dtype, int kind, int is_query, int H, int L, int dh, int m, const void* x, long ld,
                        const void* w, float ratio, float eps, float* feat, void* state, void* stream);
 int vitk_favor_pos_bwd(int dtype, int kind, int is_query, int nsum, int H, int L, int dh, int m, const void* x,

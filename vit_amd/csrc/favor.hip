@@ -43,7 +43,9 @@ struct FavorParams {
     float* dksum;           // [B][H][mp]
     void *dkvt_t, *dkv_t;   // T copies of dKV in both layouts (written by the q-side backward)
     float *kv32, *dkv32;    // fp32 [B][H][mp][dhp] copies: the two cancelling products of the backward use them
-    float* esum;            // global sum of the key-side exp gradients
+    float* esum;            // partial sums of the key-side exp gradients: [nesum] (one per (b, h); per (l, h) for the
+                            // position tables), added up by favor_fix -- one shared address would serialise ~25k atomics
+    int nesum;
     void *dq, *dk, *dv;
     long ld_d;
     // position features (DisentangledSelfAttentionPerformer): q' += pq[l][h][.], k' += pk[l][h][.]  (fp32 [L][H][mp],
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256) void favor_kmax_kernel(const FavorParams p) {
         const unsigned long long other = __shfl_xor(best, o, 64);
         best = other > best ? other : best;
     }
-    if (lane == 0) atomicMax(p.kmax, best);
+    // most waves lose against the running maximum: read it first (a stale value only costs a spare atomic)
+    if (lane == 0 && best > __atomic_load_n(p.kmax, __ATOMIC_RELAXED)) atomicMax(p.kmax, best);
 }
 
 // ------------------------------------------------------------------ KV, ksum
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) void favor_bwd_kv_kernel(const FavorParams p) 
     esum_l += __shfl_xor(esum_l, 32, 64);
     if (p.kind == FAVOR_SOFTMAX) {
         float tot = wave_sum(esum);
-        if (lane == 0) atomicAdd(p.esum, tot);
+        if (lane == 0) atomicAdd(p.esum + (long)b * p.H + h, tot);
     }
     const float ddiag = p.kind == FAVOR_SOFTMAX ? -esum_l * p.diag_c : 0.f;
     T* DK = reinterpret_cast<T*>(p.dk) + ((long)b * L + l) * p.ld_d + h * dh;
@@ -718,7 +721,9 @@ __global__ void favor_fix_kernel(const FavorParams p) {
     const unsigned long long t = idx / p.m;
     const int h = t % p.H;
     const long bl = t / p.H;
-    const float s = *p.esum;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < p.nesum; i += 64) s += p.esum[i];      // launched with one wave
+    s = wave_sum(s);
     const T* W = reinterpret_cast<const T*>(p.w);
     T* DK = reinterpret_cast<T*>(p.dk) + bl * p.ld_d + h * p.dh;
     for (int d = threadIdx.x; d < p.dh; d += blockDim.x)
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(64) void favor_pos_fwd_kernel(const FavorParams p, 
             const unsigned long long other = __shfl_xor(best, o, 64);
             best = other > best ? other : best;
         }
-        if (lane == 0) atomicMax(p.kmax, best);
+        if (lane == 0 && best > __atomic_load_n(p.kmax, __ATOMIC_RELAXED)) atomicMax(p.kmax, best);
         return;
     }
     const float diag = rsum * p.diag_c;
@@ -798,48 +803,80 @@ __global__ __launch_bounds__(64) void favor_pos_fwd_kernel(const FavorParams p, 
     }
 }
 
-// dx[l][h][.] from G[l][h][.] = sum_b dfeat[b][l][h][.]; the key side's global-max term is applied by favor_fix
+// dx[l][h][.] from G[l][h][.] = sum_b dfeat[b][l][h][.]; the key side's global-max term is applied by favor_fix.
+// One workgroup of 4 waves per (l, h): all lanes share the sum over b (with mp = 16 a wave covers 4 values of b
+// per pass), wave 0 goes back through the feature map, every thread then takes columns of dx.
 template <typename T>
-__global__ __launch_bounds__(64) void favor_pos_bwd_kernel(const FavorParams p, int is_query, const float* __restrict__ dfeat,
-                                                           int nsum) {
+__global__ __launch_bounds__(256) void favor_pos_bwd_kernel(const FavorParams p, int is_query, const float* __restrict__ dfeat,
+                                                            int nsum) {
+    __shared__ float gs[4][64 * POS_MJ];
     __shared__ float es[64 * POS_MJ];
-    const int lane = threadIdx.x, h = blockIdx.x, l = blockIdx.y;
-    const T* x = reinterpret_cast<const T*>(p.q) + (long)l * p.ld + h * p.dh;
+    __shared__ float ddiag_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x, l = blockIdx.y;
     const T* W = reinterpret_cast<const T*>(p.w);
-    float dd[POS_MJ], rsum;
-    pos_dd<T>(dd, rsum, x, W, p.dh, p.m, lane);
-    const float diag = rsum * p.diag_c;
-    const float stab = pos_stab(p, dd, is_query, lane);
-    float e[POS_MJ];
-    float esum = 0.f;
+    {
+        const int fp = p.mp < 64 ? p.mp : 64;          // features a wave covers per pass (mp is 16, 64 or 256)
+        const int per = 64 / fp;                       // values of b per wave and pass
+        const int mi0 = lane % fp, bsub = lane / fp;
+        float acc[POS_MJ];
 #pragma unroll
-    for (int j = 0; j < POS_MJ; ++j) {
-        const int mi = lane + 64 * j;
-        e[j] = 0.f;
-        if (mi < p.m) {
-            float gs = 0.f;
-            for (int b = 0; b < nsum; ++b) gs += dfeat[(((long)b * p.L + l) * p.H + h) * p.mp + mi];
-            e[j] = gs * feat_grad(p.kind, dd[j], diag, stab, p.ratio);
-            esum += e[j];
-        }
-    }
-    esum = wave_sum(esum);
-    float ddiag = 0.f;
-    if (p.kind == FAVOR_SOFTMAX) {
-        ddiag = -esum * p.diag_c;
-        if (is_query) {
+        for (int j = 0; j < POS_MJ; ++j) acc[j] = 0.f;
+        const float* src = dfeat + ((long)l * p.H + h) * p.mp;
+        const long bstride = (long)p.L * p.H * p.mp;
+        for (int b = wave * per + bsub; b < nsum; b += 4 * per) {
 #pragma unroll
             for (int j = 0; j < POS_MJ; ++j)
-                if (lane + 64 * j < p.m && dd[j] == stab) e[j] -= esum;
-        } else if (lane == 0) {
-            atomicAdd(p.esum, esum);
+                if (mi0 + 64 * j < p.mp) acc[j] += src[b * bstride + mi0 + 64 * j];
+        }
+        if (fp == 16) {
+            acc[0] += __shfl_xor(acc[0], 16, 64);
+            acc[0] += __shfl_xor(acc[0], 32, 64);
+        }
+        if (bsub == 0) {
+#pragma unroll
+            for (int j = 0; j < POS_MJ; ++j)
+                if (mi0 + 64 * j < p.mp) gs[wave][mi0 + 64 * j] = acc[j];
         }
     }
-#pragma unroll
-    for (int j = 0; j < POS_MJ; ++j) es[lane + 64 * j] = e[j];
     __syncthreads();
+    if (wave == 0) {
+        const T* x = reinterpret_cast<const T*>(p.q) + (long)l * p.ld + h * p.dh;
+        float dd[POS_MJ], rsum;
+        pos_dd<T>(dd, rsum, x, W, p.dh, p.m, lane);
+        const float diag = rsum * p.diag_c;
+        const float stab = pos_stab(p, dd, is_query, lane);
+        float e[POS_MJ];
+        float esum = 0.f;
+#pragma unroll
+        for (int j = 0; j < POS_MJ; ++j) {
+            const int mi = lane + 64 * j;
+            e[j] = 0.f;
+            if (mi < p.m) {
+                const float g = gs[0][mi] + gs[1][mi] + gs[2][mi] + gs[3][mi];
+                e[j] = g * feat_grad(p.kind, dd[j], diag, stab, p.ratio);
+                esum += e[j];
+            }
+        }
+        esum = wave_sum(esum);
+        float ddiag = 0.f;
+        if (p.kind == FAVOR_SOFTMAX) {
+            ddiag = -esum * p.diag_c;
+            if (is_query) {
+#pragma unroll
+                for (int j = 0; j < POS_MJ; ++j)
+                    if (lane + 64 * j < p.m && dd[j] == stab) e[j] -= esum;
+            } else if (lane == 0) {
+                p.esum[(long)l * p.H + h] = esum;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < POS_MJ; ++j) es[lane + 64 * j] = e[j];
+        if (lane == 0) ddiag_s = ddiag;
+    }
+    __syncthreads();
+    const float ddiag = ddiag_s;
     T* DX = reinterpret_cast<T*>(p.dk) + (long)l * p.ld_d + h * p.dh;
-    for (int d = lane; d < p.dh; d += 64) {
+    for (int d = tid; d < p.dh; d += 256) {
         float sacc = ddiag;
         for (int mi = 0; mi < p.m; ++mi) sacc += es[mi] * to_f32<T>(W[(long)mi * p.dh + d]);
         DX[d] = from_f32<T>(sacc);
@@ -876,7 +913,7 @@ template <typename T, int DKB, int MT> void launch_fwd(const FavorParams& p, hip
 template <typename T, int DKB, int MT> void launch_bwd(const FavorParams& p, hipStream_t st) {
     using C = ACfg<T, DKB>;
     constexpr int MP = 16 * MT;
-    if (p.kind == FAVOR_SOFTMAX) (void)vitk_zero_async(p.esum, 4, 4, 1, st);
+    if (p.kind == FAVOR_SOFTMAX) (void)vitk_zero_async(p.esum, 4 * (size_t)p.nesum, 4 * (size_t)p.nesum, 1, st);
     const size_t lds_q = (size_t)(32 * DKB * (MP + 8) + 4 * 16 * C::ASTR) * sizeof(T) +
                          (size_t)(32 * DKB * (MP + 4) + MP + 4 * 64) * 4;
     const size_t lds_k = (size_t)(32 * DKB * (MP + 8)) * sizeof(T);
@@ -918,8 +955,8 @@ void dispatch(const FavorParams& p, int dtype, bool bwd, hipStream_t st) {
 }  // namespace
 
 // Workspace layout (bytes, all 256-byte aligned), esz = element size of T, mp = 16 * MT, dhp = 32 * DKB:
-//   kmax (8) | esum (4) | ksum fp32 [B*H*mp] | dksum fp32 [B*H*mp] | KVT T [B*H*dh*mp] | KV T [B*H*mp*dhp]
-//   | dKVT T | dKV T | KV fp32 [B*H*mp*dhp] | dKV fp32
+//   kmax (8) | ksum fp32 [B*H*mp] | dksum fp32 [B*H*mp] | KVT T [B*H*dh*mp] | KV T [B*H*mp*dhp]
+//   | dKVT T | dKV T | KV fp32 [B*H*mp*dhp] | dKV fp32 | esum fp32 [B*H]
 // The forward fills kmax, ksum, KVT, KV; the backward reads them, so the SAME workspace must be
 // passed to both calls of one step (it is the saved state of the op).
 extern "C" long vitk_favor_workspace_bytes(int dtype, int B, int H, int dh, int m) {
@@ -927,7 +964,8 @@ extern "C" long vitk_favor_workspace_bytes(int dtype, int B, int H, int dh, int 
     const long mp = 16 * pick_mt(m), dhp = 32 * ((dh + 31) / 32);
     const long bh = (long)B * H;
     auto al = [](long x) { return (x + 255) / 256 * 256; };
-    return 256 + 2 * al(bh * mp * 4) + 2 * al(bh * dh * mp * esz) + 2 * al(bh * mp * dhp * esz) + 2 * al(bh * mp * dhp * 4);
+    return 256 + 2 * al(bh * mp * 4) + 2 * al(bh * dh * mp * esz) + 2 * al(bh * mp * dhp * esz) + 2 * al(bh * mp * dhp * 4) +
+           al(bh * 4);
 }
 
 static int favor_setup(FavorParams& p, int dtype, int kind, int B, int H, int L, int dh, int m, float ratio, float eps,
@@ -938,7 +976,6 @@ static int favor_setup(FavorParams& p, int dtype, int kind, int B, int H, int L,
     auto al = [](long x) { return (x + 255) / 256 * 256; };
     char* ws = reinterpret_cast<char*>(workspace);
     p.kmax = reinterpret_cast<unsigned long long*>(ws);
-    p.esum = reinterpret_cast<float*>(ws + 8);
     ws += 256;
     p.ksum = reinterpret_cast<float*>(ws); ws += al(bh * mp * 4);
     p.dksum = reinterpret_cast<float*>(ws); ws += al(bh * mp * 4);
@@ -947,7 +984,9 @@ static int favor_setup(FavorParams& p, int dtype, int kind, int B, int H, int L,
     p.dkvt_t = ws; ws += al(bh * dh * mp * esz);
     p.dkv_t = ws; ws += al(bh * mp * dhp * esz);
     p.kv32 = reinterpret_cast<float*>(ws); ws += al(bh * mp * dhp * 4);
-    p.dkv32 = reinterpret_cast<float*>(ws);
+    p.dkv32 = reinterpret_cast<float*>(ws); ws += al(bh * mp * dhp * 4);
+    p.esum = reinterpret_cast<float*>(ws);
+    p.nesum = (int)bh;
     p.dkvt = nullptr;
     p.B = B; p.H = H; p.L = L; p.dh = dh; p.m = m; p.mp = (int)mp; p.dhp = (int)dhp;
     p.kind = kind; p.ratio = ratio; p.eps = eps;
@@ -1049,6 +1088,7 @@ extern "C" int vitk_favor_pos_attn_bwd(int dtype, int kind, int B, int H, int L,
 
 // Row pitch (floats) of the position-feature tables and of dnq / dnk for m random features.
 extern "C" int vitk_favor_feature_pitch(int m) { return 16 * pick_mt(m); }
+extern "C" long vitk_favor_pos_state_bytes(int H, int L) { return 64 + 4 * (long)H * L; }
 
 #define FAVOR_POS_CHECKS(name)                                                                                     \
     VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, name ": bad dtype");                                   \
@@ -1062,7 +1102,8 @@ static void favor_pos_params(FavorParams& p, int kind, int H, int L, int dh, int
                              float ratio, float eps, void* state) {
     p.q = x; p.ld = ld; p.w = w;
     p.kmax = reinterpret_cast<unsigned long long*>(state);
-    p.esum = reinterpret_cast<float*>(reinterpret_cast<char*>(state) + 8);
+    p.esum = reinterpret_cast<float*>(reinterpret_cast<char*>(state) + 64);
+    p.nesum = L * H;
     p.B = 1; p.H = H; p.L = L; p.dh = dh; p.m = m; p.mp = 16 * pick_mt(m);
     p.kind = kind; p.ratio = ratio; p.eps = eps;
     p.diag_c = 0.5f / sqrtf((float)dh);
@@ -1071,8 +1112,8 @@ static void favor_pos_params(FavorParams& p, int kind, int H, int L, int dh, int
 // Position-feature table: feat[l][h][.] = feature map (query form: row max; key form: max over the whole
 // [L][H][m] tensor) of x[l][h*dh ..], x = pos_query_proj / pos_key_proj of pos_embed ([L, >= H*dh] in T).
 // Replaces softmax_kernel_transformation / relu_kernel_transformation as called at
-// disentangled_transformer.py:623-641.  state: 16 bytes (256-byte buffer recommended) that keep the key
-// max / argmax for vitk_favor_pos_bwd.
+// disentangled_transformer.py:623-641.  state: vitk_favor_pos_state_bytes(H, L) bytes, 16-byte aligned: the key
+// max / argmax for vitk_favor_pos_bwd, and room for its per-(l, h) partial sums.
 extern "C" int vitk_favor_pos_fwd(int dtype, int kind, int is_query, int H, int L, int dh, int m, const void* x, long ld,
                                   const void* w, float ratio, float eps, float* feat_out, void* state,
                                   hipStream_t stream) {
@@ -1107,14 +1148,13 @@ extern "C" int vitk_favor_pos_bwd(int dtype, int kind, int is_query, int nsum, i
     FavorParams p = {};
     favor_pos_params(p, kind, H, L, dh, m, x, ld, w, ratio, eps, state);
     p.dk = dx; p.ld_d = ld_d;
-    const bool fix = kind == FAVOR_SOFTMAX && !is_query;
-    if (fix) (void)vitk_zero_async(p.esum, 4, 4, 1, stream);
+    const bool fix = kind == FAVOR_SOFTMAX && !is_query;      // every (l, h) stores its partial sum: nothing to zero
     const dim3 grid(H, L);
     if (dtype == VITK_BF16) {
-        hipLaunchKernelGGL(favor_pos_bwd_kernel<__bf16>, grid, dim3(64), 0, stream, p, is_query, dfeat, nsum);
+        hipLaunchKernelGGL(favor_pos_bwd_kernel<__bf16>, grid, dim3(256), 0, stream, p, is_query, dfeat, nsum);
         if (fix) hipLaunchKernelGGL(favor_fix_kernel<__bf16>, dim3(1), dim3(64), 0, stream, p);
     } else {
-        hipLaunchKernelGGL(favor_pos_bwd_kernel<float>, grid, dim3(64), 0, stream, p, is_query, dfeat, nsum);
+        hipLaunchKernelGGL(favor_pos_bwd_kernel<float>, grid, dim3(256), 0, stream, p, is_query, dfeat, nsum);
         if (fix) hipLaunchKernelGGL(favor_fix_kernel<float>, dim3(1), dim3(64), 0, stream, p);
     }
     VITK_CHECK_LAUNCH("vitk_favor_pos_bwd");

@@ -324,7 +324,7 @@ def favor_pos_fwd(x, H, dh, w, kind, is_query, ratio, eps):
         raise ValueError('favor_pos: x must be 2-D rows, w contiguous [m, dh], both in the compute dtype')
     L, m = x.shape[0], w.shape[0]
     feat = torch.empty(L, H, favor_feature_pitch(m), device=x.device, dtype=torch.float32)
-    state = torch.empty(64, device=x.device, dtype=torch.float32)
+    state = torch.empty(lib().vitk_favor_pos_state_bytes(H, L), device=x.device, dtype=torch.uint8)
     st = lib().vitk_favor_pos_fwd(_dt(x), kind, int(is_query), H, L, dh, m, x.data_ptr(), x.stride(0), w.data_ptr(),
                                   float(ratio), float(eps), feat.data_ptr(), state.data_ptr(), _stream())
     check(st, 'vitk_favor_pos_fwd')
