@@ -178,6 +178,16 @@ int vitk_favor_pos_attn_bwd(int dtype, int kind, int B, int H, int L, int dh, in
                             const float* pk, const void* out, const void* dout, long ldo, void* dq, void* dk,
                             void* dv, long ld_d, float* dnq, float* dnk, void* workspace, void* stream);
 
+/* Label-smoothing cross entropy, mean over the batch: criterion = LabelSmoothingCrossEntropy(smoothing)
+ * (train.py:273, applied :541; timm 0.4.5 loss/cross_entropy.py): (1-s) * NLL + s * mean_c(-log p).
+ * logits [B, C] fp32 (row pitch ld / ld_d), target [B] int64.  fwd: loss[0] (scalar), loss_rows [B], lse [B];
+ * bwd: dlogits = gout * d loss / d logits with gout one fp32 value in device memory.  A target outside
+ * [0, C) makes the loss NaN (torch raises there). */
+int vitk_ce_smooth_fwd(int B, int C, const float* logits, long ld, const long long* target, float smoothing,
+                       float* loss_rows, float* lse, float* loss, void* stream);
+int vitk_ce_smooth_bwd(int B, int C, const float* logits, long ld, const long long* target, float smoothing,
+                       const float* lse, const float* gout, float* dlogits, long ld_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

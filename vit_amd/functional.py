@@ -738,3 +738,29 @@ def favor_attention(qkv, w, B, L, H, dh, kernel, ratio):
     """kernel: 'softmax' (eps 1e-6) or 'relu' (eps 1e-3), as the reference's two feature maps."""
     kind, eps = _favor_kind(kernel)
     return FavorAttentionFn.apply(qkv, w.to(qkv.dtype).contiguous(), B, L, H, dh, kind, float(ratio), eps)
+
+
+# --------------------------------------------------------------------------- loss
+class LabelSmoothingCEFn(torch.autograd.Function):
+    """timm 0.4.5 LabelSmoothingCrossEntropy (train.py:273,541), mean over the batch: two small HIP kernels forward,
+    one backward (the softmax is recomputed from the saved log-sum-exp)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, smoothing):
+        loss, lse = ops.ce_smooth_fwd(logits, target, smoothing)
+        ctx.save_for_backward(logits, target, lse)
+        ctx.smoothing = smoothing
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        return ops.ce_smooth_bwd(logits, target, ctx.smoothing, lse, g.float().contiguous()), None, None
+
+
+def label_smoothing_ce(logits, target, smoothing=0.1):
+    if logits.dtype != torch.float32 or logits.stride(-1) != 1:
+        logits = logits.float().contiguous()
+    if target.dtype != torch.int64:
+        target = target.long()
+    return LabelSmoothingCEFn.apply(logits, target.contiguous(), float(smoothing))

@@ -381,3 +381,30 @@ def favor_pos_attn_bwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, pq, pk, ou
                                        _stream())
     check(st, 'vitk_favor_pos_attn_bwd')
     return dnq, dnk
+
+
+def ce_smooth_fwd(logits, target, smoothing):
+    """Mean label-smoothing cross entropy of fp32 logits [B, C] vs int64 target [B]: (loss 0-dim, lse [B])."""
+    _req_cuda(logits, target)
+    if logits.dim() != 2 or logits.dtype != torch.float32 or logits.stride(1) != 1 or logits.numel() == 0:
+        raise ValueError('ce_smooth: logits must be non-empty fp32 [B, C] rows')
+    if target.dtype != torch.int64 or target.shape != (logits.shape[0],) or not target.is_contiguous():
+        raise ValueError('ce_smooth: target must be contiguous int64 [B]')
+    B, C = logits.shape
+    buf = torch.empty(2 * B + 1, device=logits.device, dtype=torch.float32)
+    st = lib().vitk_ce_smooth_fwd(B, C, logits.data_ptr(), logits.stride(0), target.data_ptr(), float(smoothing),
+                                  buf.data_ptr(), buf[B:].data_ptr(), buf[2 * B:].data_ptr(), _stream())
+    check(st, 'vitk_ce_smooth_fwd')
+    return buf[2 * B], buf[B:2 * B]
+
+
+def ce_smooth_bwd(logits, target, smoothing, lse, gout):
+    _req_cuda(logits, target, lse, gout)
+    if gout.dtype != torch.float32 or gout.numel() != 1:
+        raise ValueError('ce_smooth_bwd: the upstream gradient must be one fp32 value')
+    B, C = logits.shape
+    d = torch.empty(B, C, device=logits.device, dtype=torch.float32)
+    st = lib().vitk_ce_smooth_bwd(B, C, logits.data_ptr(), logits.stride(0), target.data_ptr(), float(smoothing),
+                                  lse.data_ptr(), gout.data_ptr(), d.data_ptr(), C, _stream())
+    check(st, 'vitk_ce_smooth_bwd')
+    return d

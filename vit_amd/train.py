@@ -5,8 +5,8 @@
 Not restated: datasets, wandb, checkpoints, the eval loop.
 """
 import torch
-import torch.nn.functional as F
 
+from . import functional as VF
 from . import model as M
 from .disentangled_transformer.disentangled_transformer import DisentangledTransformer
 from .precision import set_compute_dtype
@@ -24,10 +24,10 @@ PRESETS = {
 
 
 def label_smoothing_ce(logits, target, smoothing=0.1):
-    """timm 0.4.5 LabelSmoothingCrossEntropy (train.py:273): (1-s) * NLL + s * mean(-log p)."""
-    logp = F.log_softmax(logits.float(), dim=-1)
-    nll = -logp.gather(-1, target[:, None]).squeeze(1)
-    return ((1.0 - smoothing) * nll + smoothing * (-logp.mean(-1))).mean()
+    """timm 0.4.5 LabelSmoothingCrossEntropy (train.py:273): (1-s) * NLL + s * mean(-log p), on the HIP
+    kernels of csrc/loss.hip (forward and backward); logits [B, C] on the GPU."""
+    return VF.label_smoothing_ce(logits if logits.dim() == 2 else logits.reshape(-1, logits.shape[-1]), target.reshape(-1),
+                                 smoothing)
 
 
 def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, num_classes=1000,
