@@ -98,6 +98,12 @@ int vitk_patchify(int img_dtype, int out_dtype, int B, int C, int H, int W, int 
                   void* out, void* stream);
 int vitk_unpatchify(int dtype, int B, int C, int H, int W, int P, const void* dpatch, float* dimg,
                     void* stream);
+/* The same gather from raw uint8 pixels with the loader's ToTensor + Normalize(mean, std) folded in
+ * (train.py:340-341, 362-363, 385: x / 255 then (x - mean[c]) / std[c]).  img: [B][C][H][W], or
+ * [B][H][W][C] with channels_last != 0; mean / std: C (<= 4) floats in HOST memory.  fp32 output equals
+ * torchvision's arithmetic bit for bit. */
+int vitk_patchify_u8(int out_dtype, int B, int C, int H, int W, int P, int channels_last, const unsigned char* img,
+                     const float* mean, const float* std, void* out, void* stream);
 /* x[b][0][:] = cls + pos[0] (pos may be NULL): torch.cat((cls_tokens, x)) [+ pos_embed]
  * (model.py:54-55; timm_locality_aware_transformer.py:136-138). */
 int vitk_cls_rows(int dtype, int B, int N, int D, const float* cls, const float* pos, void* x, void* stream);

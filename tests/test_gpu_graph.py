@@ -5,14 +5,22 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model():
+def _model(variant='disentangled_lai_attention'):
     from vit_amd.train import build_model
     torch.manual_seed(0)
-    return build_model('disentangled_lai_attention', 'S', img_size=32, patch_size=4, num_classes=10,
-                       mask_epochs=[10, 20, 30, 40], depth=2, dim=128, mlp=256, heads=4)
+    net = build_model(variant, 'S', img_size=32, patch_size=4, num_classes=10,
+                      mask_epochs=[10, 20, 30, 40], depth=2, dim=128, mlp=256, heads=4)
+    if variant == 'disentangled_performer':      # the random features are drawn at first use: fix them per model
+        with torch.no_grad():                    # pos_embed is trained by this variant only; zeros would make the
+            net.pos_embed.normal_(0, 0.5, generator=torch.Generator(device='cuda').manual_seed(7))   # max-norm check moot
+        for i, lay in enumerate(net.transformer.encoder.layers):
+            g = torch.Generator().manual_seed(100 + i)
+            lay.dis_attn.w = (torch.randn(16, 32, generator=g) * 0.5).cuda()
+    return net
 
 
-def test_graphed_step_matches_eager():
+@pytest.mark.parametrize('variant,epoch', [('disentangled_lai_attention', 30), ('disentangled_performer', None)])
+def test_graphed_step_matches_eager(variant, epoch):
     from vit_amd import optim
     from vit_amd.graph import GraphedTrainStep
     from vit_amd.train import train_step
@@ -21,17 +29,17 @@ def test_graphed_step_matches_eager():
     tgts = [torch.randint(0, 10, (8,), device='cuda') for _ in range(4)]
     warm = 2
 
-    net_e = _model()
+    net_e = _model(variant)
     opt_e = optim.AdamW(net_e.parameters(), lr=1e-3)
     losses_e = []
     for _ in range(warm):                                # the graph's warm-up steps, eagerly
-        train_step(net_e, opt_e, imgs[0], tgts[0], 30)
+        train_step(net_e, opt_e, imgs[0], tgts[0], epoch)
     for x, y in zip(imgs, tgts):
-        losses_e.append(train_step(net_e, opt_e, x, y, 30).item())
+        losses_e.append(train_step(net_e, opt_e, x, y, epoch).item())
 
-    net_g = _model()
+    net_g = _model(variant)
     opt_g = optim.AdamW(net_g.parameters(), lr=1e-3, capturable=True)
-    gs = GraphedTrainStep(net_g, opt_g, imgs[0], tgts[0], epoch=30, warmup=warm)
+    gs = GraphedTrainStep(net_g, opt_g, imgs[0], tgts[0], epoch=epoch, warmup=warm)
     losses_g = [gs.step(x, y).item() for x, y in zip(imgs, tgts)]
 
     for a, b in zip(losses_e, losses_g):
@@ -39,3 +47,8 @@ def test_graphed_step_matches_eager():
     for (n, p), q in zip(net_e.named_parameters(), net_g.parameters()):
         err = (p - q).abs().max().item() / p.abs().max().clamp_min(1e-6).item()
         assert err < 2e-2, (n, err)
+    if variant == 'disentangled_performer':      # the parameter only this variant trains: both runs moved it the same way
+        p0 = _model(variant).pos_embed
+        ue, ug = (net_e.pos_embed - p0).flatten().float(), (net_g.pos_embed - p0).flatten().float()
+        assert ue.abs().max().item() > 0
+        assert torch.nn.functional.cosine_similarity(ue, ug, dim=0).item() > 0.9

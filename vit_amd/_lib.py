@@ -33,6 +33,7 @@ _SIGNATURES = {
     'vitk_adamw': ([c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_double, c_double, c_double, c_int,
                     c_vp, c_long, c_vp, c_long, c_vp], c_int),
     'vitk_patchify': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp], c_int),
+    'vitk_patchify_u8': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
     'vitk_unpatchify': ([c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp], c_int),
     'vitk_cls_rows': ([c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp], c_int),
     'vitk_token_grads': ([c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp], c_int),

@@ -354,6 +354,34 @@ __global__ void patchify_kernel(const TI* __restrict__ img, T* __restrict__ out,
         out[i] = from_f32<T>(to_f32<TI>(img[(((long)b * C + c) * Hh + ph * P + py) * Ww + pw * P + px]));
     }
 }
+// The same gather from raw uint8 pixels, with ToTensor + Normalize folded in (train.py:340-341,362-363:
+// x / 255, then (x - mean[c]) / std[c], in that order and with true divisions, so fp32 output equals torchvision's
+// bit for bit).  img is [B][C][H][W] or, channels_last, [B][H][W][C] as decoders deliver it.
+struct PixelNorm {
+    float mean[4], std[4];
+};
+template <typename T>
+__global__ void patchify_u8_kernel(const unsigned char* __restrict__ img, T* __restrict__ out, int B, int C, int Hh, int Ww,
+                                   int P, int channels_last, const PixelNorm nrm) {
+    const int nph = Hh / P, npw = Ww / P;
+    const long total = (long)B * C * Hh * Ww;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = i % P;
+        long t = i / P;
+        const int py = t % P;
+        t /= P;
+        const int c = t % C;
+        t /= C;
+        const int pw = t % npw;
+        t /= npw;
+        const int ph = t % nph;
+        const int b = t / nph;
+        const int y = ph * P + py, x = pw * P + px;
+        const long src = channels_last ? (((long)b * Hh + y) * Ww + x) * C + c : (((long)b * C + c) * Hh + y) * Ww + x;
+        const float v = (float)img[src] / 255.0f;
+        out[i] = from_f32<T>((v - nrm.mean[c]) / nrm.std[c]);
+    }
+}
 // scatter-back for d(img): the exact inverse permutation
 template <typename T>
 __global__ void unpatchify_kernel(const T* __restrict__ dpatch, float* __restrict__ dimg, int B, int C, int Hh,
@@ -538,6 +566,33 @@ extern "C" int vitk_patchify(int img_dtype, int out_dtype, int B, int C, int H, 
     else { vitk_set_error("vitk_patchify: unsupported dtype pair"); return VITK_ERR_ARG; }
 #undef L
     VITK_CHECK_LAUNCH("vitk_patchify");
+    return VITK_OK;
+}
+
+// Patches straight from uint8 images: ToTensor + Normalize(mean, std) + the patch gather in one pass (1 byte read per
+// pixel instead of 4: the host sends uint8).  mean / std: C values each in HOST memory, C <= 4.
+extern "C" int vitk_patchify_u8(int out_dtype, int B, int C, int H, int W, int P, int channels_last,
+                                const unsigned char* img, const float* mean, const float* stdv, void* out,
+                                hipStream_t stream) {
+    VITK_CHECK_ARG(P > 0 && H % P == 0 && W % P == 0, "vitk_patchify_u8: image %dx%d not divisible by patch %d", H, W, P);
+    VITK_CHECK_ARG(C >= 1 && C <= 4, "vitk_patchify_u8: 1..4 channels supported, got %d", C);
+    VITK_CHECK_ARG(img && out && mean && stdv, "vitk_patchify_u8: null pointer");
+    PixelNorm nrm = {};
+    for (int c = 0; c < C; ++c) {
+        VITK_CHECK_ARG(stdv[c] != 0.f, "vitk_patchify_u8: std[%d] is zero", c);
+        nrm.mean[c] = mean[c];
+        nrm.std[c] = stdv[c];
+    }
+    const long total = (long)B * C * H * W;
+    if (total == 0) return VITK_OK;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (out_dtype == VITK_F32)
+        hipLaunchKernelGGL(patchify_u8_kernel<float>, dim3((int)blocks), dim3(256), 0, stream, img, (float*)out, B, C, H, W, P, channels_last, nrm);
+    else if (out_dtype == VITK_BF16)
+        hipLaunchKernelGGL(patchify_u8_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, stream, img, (__bf16*)out, B, C, H, W, P, channels_last, nrm);
+    else { vitk_set_error("vitk_patchify_u8: unsupported output dtype"); return VITK_ERR_ARG; }
+    VITK_CHECK_LAUNCH("vitk_patchify_u8");
     return VITK_OK;
 }
 

@@ -592,13 +592,21 @@ class PatchEmbedFn(torch.autograd.Function):
     (model.py:52-55,92-99; timm_locality_aware_transformer.py:133-138)."""
 
     @staticmethod
-    def forward(ctx, img, weight, bias, cls_token, pos_embed, dtype):
-        B, C, Hh, Ww = img.shape
+    def forward(ctx, img, weight, bias, cls_token, pos_embed, dtype, norm=None):
         D = weight.shape[0]
         P = weight.shape[2]
+        if img.dtype == torch.uint8:
+            # raw pixels: ToTensor + Normalize ride in the gather (train.py:340-341,362-363); norm = (mean, std, layout)
+            if norm is None:
+                raise ValueError('uint8 images need the input normalisation (vit_amd.data.set_input_norm)')
+            nhwc = len(norm) > 2 and norm[2] == 'nhwc'
+            B, C, Hh, Ww = (img.shape[0], img.shape[3], img.shape[1], img.shape[2]) if nhwc else img.shape
+            patches = ops.patchify_u8(img, P, dtype, norm[0], norm[1], channels_last=nhwc)
+        else:
+            B, C, Hh, Ww = img.shape
+            patches = ops.patchify(img, P, dtype)
         npatch = (Hh // P) * (Ww // P)
         N = npatch + 1
-        patches = ops.patchify(img, P, dtype)
         w2d = shadow(weight, dtype).view(D, C * P * P)
         pos_t = None
         if pos_embed is not None:
@@ -629,11 +637,13 @@ class PatchEmbedFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = shadow(weight, dtok.dtype).view(D, C * P * P)
             dimg = ops.unpatchify(_dx_nn(dpatch_rows, wt), B, C, Hh, Ww, P)
-        return (dimg, dw, db, dcls.view(1, 1, D), None if dpos is None else dpos.view(1, N, D), None)
+        return (dimg, dw, db, dcls.view(1, 1, D), None if dpos is None else dpos.view(1, N, D), None, None)
 
 
-def patch_embed(img, weight, bias, cls_token, pos_embed, dtype):
-    return PatchEmbedFn.apply(img, weight, bias, cls_token, pos_embed, dtype)
+def patch_embed(img, weight, bias, cls_token, pos_embed, dtype, norm=None):
+    """img: float [B,C,H,W] (already normalised, as the reference's loader delivers it), or uint8 [B,C,H,W] /
+    [B,H,W,C] with ``norm`` = (mean, std[, 'nchw' | 'nhwc'])."""
+    return PatchEmbedFn.apply(img, weight, bias, cls_token, pos_embed, dtype, norm)
 
 
 # --------------------------------------------------------------------------- MLP

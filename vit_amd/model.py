@@ -43,12 +43,14 @@ class VisionTransformer(ComputeDtypeMixin, nn.Module):
         self.out = nn.Linear(num_classes, num_classes)    # unused, as in the reference (:46)
 
     def forward(self, img, epoch=None):
-        self.patch_embed.check(img)
+        norm = getattr(self, 'input_norm', None)
+        self.patch_embed.check(img.permute(0, 3, 1, 2) if (img.dtype == torch.uint8 and norm and norm[2] == 'nhwc') else img)
         B = img.shape[0]
         dt = self.compute_dtype
         N = self.patch_embed.num_patches + 1
         D = self.embed_dim
-        tok = VF.patch_embed(img, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token, None, dt)
+        tok = VF.patch_embed(img, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token, None, dt,
+                             norm=norm)
         tr = self.transformer
         if hasattr(tr, 'encode2d'):
             if getattr(tr, 'uses_pos_embed', False):      # DisentangledSelfAttentionPerformer reads it (dis :614)

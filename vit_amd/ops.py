@@ -224,6 +224,29 @@ def patchify(img, P, out_dtype):
     return out
 
 
+def patchify_u8(img, P, out_dtype, mean, std, channels_last=False):
+    """Patches [B*nph*npw, C*P*P] from uint8 images ([B,C,H,W], or [B,H,W,C] when channels_last) with
+    x/255 and (x - mean[c]) / std[c] applied on the way (the loader's ToTensor + Normalize)."""
+    import ctypes
+    _req_cuda(img)
+    if img.dtype != torch.uint8 or img.dim() != 4:
+        raise ValueError('patchify_u8: uint8 [B,C,H,W] / [B,H,W,C] images expected')
+    if channels_last:
+        B, H, W, C = img.shape
+    else:
+        B, C, H, W = img.shape
+    if len(mean) != C or len(std) != C:
+        raise ValueError(f'patchify_u8: {C} channels need {C} mean / std values')
+    img = img.contiguous()
+    out = torch.empty(B * (H // P) * (W // P), C * P * P, device=img.device, dtype=out_dtype)
+    arr = ctypes.c_float * C
+    m, s = arr(*[float(v) for v in mean]), arr(*[float(v) for v in std])
+    check(lib().vitk_patchify_u8(_dt(out), B, C, H, W, P, int(bool(channels_last)), img.data_ptr(),
+                                 ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), out.data_ptr(),
+                                 _stream()), 'vitk_patchify_u8')
+    return out
+
+
 def unpatchify(dpatch, B, C, H, W, P):
     _req_cuda(dpatch)
     dpatch = dpatch.contiguous()

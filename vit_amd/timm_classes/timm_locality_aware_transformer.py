@@ -183,13 +183,14 @@ class VisionTransformerLAI(ComputeDtypeMixin, nn.Module):
 
     def forward_features(self, x, epoch):
         _check_p0(self, self.pos_drop.p)
-        self.patch_embed.check(x)
+        norm = getattr(self, 'input_norm', None)
+        self.patch_embed.check(x.permute(0, 3, 1, 2) if (x.dtype == torch.uint8 and norm and norm[2] == 'nhwc') else x)
         B = x.shape[0]
         dt = self.compute_dtype
         N = self.patch_embed.num_patches + 1
         D = self.embed_dim
         tok = VF.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token,
-                             self.pos_embed, dt)
+                             self.pos_embed, dt, norm=norm)
         for blk in self.blocks:
             tok = blk.forward2d(tok, B, N, epoch)
         cls = tok.view(B, N, D)[:, 0]           # LayerNorm is row-wise: normalise the class rows only
