@@ -62,9 +62,32 @@ class AdamW(torch.optim.Optimizer):
             return self.capturable          # one row; a ragged length takes the kernel's element-wise form
         return (p.numel() // p.shape[0]) % 4 == 0
 
+    def state_dict(self):
+        """torch.optim.AdamW's layout (state: step / exp_avg / exp_avg_sq; groups: lr, betas, eps, weight_decay, ...):
+        a checkpoint written here loads into torch.optim.AdamW and the other way round (train.py:589)."""
+        sd = super().state_dict()
+        sd['state'] = {k: {n: v for n, v in st.items() if n != 'native'} for k, st in sd['state'].items()}
+        sd['param_groups'] = [{n: v for n, v in g.items() if n not in ('dyn', 'dyn_host')} for g in sd['param_groups']]
+        return sd
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self.__dict__.get('_plans', {}).clear()      # the moment buffers were replaced
+        t = 0
+        for group in self.param_groups:
+            group.pop('dyn', None)                   # device scalars are rebuilt by update_dyn()
+            group.pop('dyn_host', None)
+            for p in group['params']:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                st['native'] = self._native(p)
+                for n in ('exp_avg', 'exp_avg_sq'):
+                    st[n] = st[n].to(device=p.device, dtype=torch.float32).contiguous()
+                step = torch.as_tensor(st['step'], dtype=torch.float32)
+                st['step'] = step.detach().cpu().reshape(()) if st['native'] else step.to(p.device).reshape(())
+                t = max(t, int(st['step'].item()))
+        self._t = t
 
     def _plan(self, p, st):
         """Launch arguments of one native parameter that do not change from step to step (everything
