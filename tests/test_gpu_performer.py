@@ -241,6 +241,36 @@ def test_dis_performer_model_vs_reference_golden(dtype):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+@pytest.mark.parametrize('kernel,m,B,L,H,dh', [('softmax', 16, 37, 197, 3, 64), ('softmax', 256, 9, 100, 2, 64),
+                                                 ('relu', 48, 21, 65, 4, 32), ('softmax', 64, 130, 50, 2, 48)])
+def test_favor_pos_attention_large_batch_vs_oracle(kernel, m, B, L, H, dh, dtype):
+    """Batches beyond the goldens' (B <= 3): the backward's reduction over b (4 waves, several b per pass when
+    mp = 16) and every feature pitch (16 / 64 / 256), kernel vs the CPU oracle's formulas on the same inputs."""
+    from vit_amd import functional as VF
+    D = H * dh
+    gen = torch.Generator().manual_seed(B * L + m)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    bf = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    qkv, posqk, gout = bf(rnd(B * L, 3 * D) * 0.5), bf(rnd(L, 2 * D) * 0.5), rnd(B * L, D)
+    w = bf(R.gaussian_orthogonal_random_matrix(m, dh, generator=torch.Generator().manual_seed(2)))
+    ratio = m ** -0.25
+    feats = (lambda d, isq: R.favor_softmax_features(d, w, isq, ratio)) if kernel == 'softmax' else \
+        (lambda d, isq: R.favor_relu_features(d, w, ratio))
+    qr, pr = qkv.clone().requires_grad_(True), posqk.clone().requires_grad_(True)
+    q, k, v = (qr[:, i * D:(i + 1) * D].view(B, L, H, dh) for i in range(3))
+    Pq, Pk = feats(pr[:, :D].view(1, L, H, dh), True), feats(pr[:, D:].view(1, L, H, dh), False)
+    ref = R.favor_linear_attention(feats(q, True) + Pq, feats(k, False) + Pk, v).reshape(B * L, D)
+    (ref * gout).sum().backward()
+    xg = qkv.clone().cuda().to(dtype).requires_grad_(True)
+    pg = posqk.clone().cuda().to(dtype).requires_grad_(True)
+    out = VF.favor_pos_attention(xg, pg, w.cuda(), B, L, H, dh, kernel, ratio)
+    (out.float() * gout.cuda()).sum().backward()
+    for name, a, b_ in (('out', out.detach(), ref.detach()), ('dqkv', xg.grad, qr.grad), ('dpos', pg.grad, pr.grad)):
+        a = a.float().cpu()
+        assert ok(a, b_, dtype, 2), (name, relerr(a, b_), l2err(a, b_))
+
+
 def test_favor_pos_rejects():
     from vit_amd import ops
     x = torch.randn(10, 64, device='cuda')
