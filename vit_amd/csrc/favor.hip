@@ -743,13 +743,18 @@ __device__ __forceinline__ void pos_dd(float (&dd)[POS_MJ], float& rsum, const T
     rsum = 0.f;
 #pragma unroll
     for (int j = 0; j < POS_MJ; ++j) dd[j] = 0.f;
-    for (int d = 0; d < dh; ++d) {
-        const float xv = to_f32<T>(x[d]);
-        rsum += xv;
+    // four elements per step (dh % 4 == 0, rows 8- / 16-byte aligned: host-checked): 4x fewer dependent loads
+#pragma unroll 4
+    for (int d = 0; d < dh; d += 4) {
+        const f32x4 xv = load4<T>(x + d);
+        rsum += (xv[0] + xv[1]) + (xv[2] + xv[3]);
 #pragma unroll
         for (int j = 0; j < POS_MJ; ++j) {
             const int mi = lane + 64 * j;
-            if (mi < m) dd[j] += xv * to_f32<T>(W[(long)mi * dh + d]);
+            if (mi < m) {
+                const f32x4 wv = load4<T>(W + (long)mi * dh + d);
+                dd[j] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+            }
         }
     }
 }
@@ -1096,7 +1101,10 @@ extern "C" long vitk_favor_pos_state_bytes(int H, int L) { return 64 + 4 * (long
     VITK_CHECK_ARG(H > 0 && L > 0 && H <= 65535 && L <= 65535, name ": empty or oversized problem");               \
     VITK_CHECK_ARG(dh > 0 && dh <= 64, name ": head dim %d unsupported", dh);                                      \
     VITK_CHECK_ARG(m > 0 && m <= 256, name ": 1..256 random features supported, got %d", m);                       \
-    VITK_CHECK_ARG(x && w && state && f16al(state) && ld >= (long)H * dh, name ": bad x / w / state")
+    VITK_CHECK_ARG(x && w && state && f16al(state) && ld >= (long)H * dh, name ": bad x / w / state");             \
+    VITK_CHECK_ARG(dh % 4 == 0 && f16al(x) && f16al(w) && (ld * (dtype == VITK_BF16 ? 2 : 4)) % 16 == 0 &&         \
+                       (dh * (dtype == VITK_BF16 ? 2 : 4)) % 8 == 0,                                               \
+                   name ": x / w rows must be 16-byte aligned, head dim a multiple of 4")
 
 static void favor_pos_params(FavorParams& p, int kind, int H, int L, int dh, int m, const void* x, long ld, const void* w,
                              float ratio, float eps, void* state) {
