@@ -79,6 +79,10 @@ def cpu_baseline(args, variant, preset, img, patch, classes, w):
         net = R.RefVisionTransformerLAI(img_size=img, patch_size=patch, num_classes=classes, embed_dim=p['dim'],
                                         depth=depth, num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'],
                                         mask_epochs=me)
+    elif variant == 'disentangled_performer':
+        tr = R.RefDisentangledPerformerTransformer(d_model=p['dim'], nhead=p['heads'], num_encoder_layers=depth,
+                                                   dim_feedforward=p['mlp'], normalize_before=True, norf=16)
+        net = R.RefVisionTransformer(img_size=img, patch_size=patch, num_classes=classes, transformer=tr)
     elif variant == 'transformer':
         tr = R.RefTransformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
                               num_encoder_layers=depth, normalize_before=True)
@@ -234,7 +238,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and 'performer' not in variant:   # no oracle model of the FAVOR+ models' shells
+        if world == 1 and not args.no_cpu_baseline and not variant.startswith('performer'):   # no oracle model of config 5's timm shell
             cpu = cpu_baseline(args, variant, preset, img, patch, classes, w)
         out = {
             'metric': 'train images/sec (node) ViT-B/16-224 LAI+Dis' if args.workload == 'dislai_b16'

@@ -522,6 +522,39 @@ class RefDisentangledPerformerLayer(nn.Module):
         return self.layer_norm_out(self.dense_out(F.gelu(self.dense_intermediate(a))) + a)
 
 
+class RefDisentangledPerformerTransformer(nn.Module):
+    """DisentangledTransformer(performers=True) (dis:15-128 around the layer above): pos_embed [1,L,D] is permuted to
+    [L,1,D] (:69) and handed to every layer; final LayerNorm when normalize_before; output [L,B,D] (:73).  The
+    relative table and its LayerNorm exist as parameters (:97-99) and are never read by this variant."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, normalize_before=False,
+                 norf=32, kernel='softmax'):
+        super().__init__()
+        enc = nn.Module()
+        enc.layers = nn.ModuleList([RefDisentangledPerformerLayer(d_model, nhead, dim_feedforward, norf, kernel)
+                                    for _ in range(num_encoder_layers)])
+        enc.rel_embeddings = nn.Embedding(d_model * 2, d_model)
+        enc.LayerNorm = nn.LayerNorm(d_model)
+        if normalize_before:
+            enc.norm = nn.LayerNorm(d_model)
+        self.has_norm = normalize_before
+        self.encoder = enc
+        self.d_model = d_model
+        self.nhead = nhead
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, pos_embed):
+        pos = pos_embed.permute(1, 0, 2)
+        out = src
+        for layer in self.encoder.layers:
+            out = layer(out, pos)
+        if self.has_norm:
+            out = self.encoder.norm(out)
+        return out.permute(1, 0, 2)
+
+
 class RefMultiheadAttentionPerformer(nn.MultiheadAttention):
     """MultiheadAttentionPerformer (model.py:248-388): [L,B,E] layout, packed in_proj,
     softmax-kernel ratio m^-1/2 (:323) but relu-kernel ratio m^-1/4 (:347)."""

@@ -198,6 +198,27 @@ def test_dis_performer_layer():
             close(v, g[pre + k], what=pre + k, rtol=5e-5)
 
 
+def test_dis_performer_model():
+    """RefVisionTransformer around RefDisentangledPerformerTransformer vs the reference's 2-layer
+    --attention disentangled_performer model: logits, d img, d pos_embed, a few weights."""
+    g = load('dis_performer.npz')
+    tr = R.RefDisentangledPerformerTransformer(d_model=128, nhead=4, num_encoder_layers=2, dim_feedforward=256,
+                                               normalize_before=True, norf=16, kernel='softmax')
+    net = R.RefVisionTransformer(img_size=32, patch_size=4, in_chans=3, num_classes=10, transformer=tr)
+    # values depend on key names and shapes only; the reference's layers also carry three unused projections
+    net.load_state_dict(gi.fill_state_dict(net.state_dict(), seed=71))
+    for i, lay in enumerate(tr.encoder.layers):
+        lay.dis_attn.w = torch.from_numpy(g[f'model_w{i}'])
+    img = gi.randn(71, 'img', 2, 3, 32, 32)
+    r = run_with_grads(lambda t: net(t), img, list(net.named_parameters()), 73, 1)
+    keys = [k[len('model_'):] for k in g.files if k.startswith('model_') and k[6:7] in 'yd']
+    assert len(keys) == 9
+    for k in keys:
+        close(r[k], g['model_' + k], what='model_' + k, rtol=1e-4)
+    unused = {n for n, p in net.named_parameters() if ('d_' + n) not in r}
+    assert unused <= set(g['model_nograd'].tolist())
+
+
 def DISPERF_LAYER_KEYS(D, F):
     """state_dict shapes of the reference's DisentangledEncoderLayer(performers=True) (values in the
     fixtures depend on key names only: golden_inputs.fill_state_dict)."""
