@@ -37,8 +37,8 @@ WORKLOADS = {
     'lai_s16': ('transformer_timm_lai', 'S', 224, 16, 1000, 128),
     'dislai_l16': ('disentangled_lai_attention', 'L', 224, 16, 1000, 64),
     'regular_cifar': ('transformer', 'cifar', 32, 4, 10, 128),
-    'performer_s16_384': ('performer_timm', 'S', 384, 16, 1000, 64),      # config 5, FAVOR+ m = 64 (GPU line only)
-    'disperf_s16': ('disentangled_performer', 'S', 224, 16, 1000, 128),   # SURVEY 8(f)-1, m = 16 (train.py:75; GPU line only)
+    'performer_s16_384': ('performer_timm', 'S', 384, 16, 1000, 64),      # config 5, FAVOR+ m = 64
+    'disperf_s16': ('disentangled_performer', 'S', 224, 16, 1000, 128),   # SURVEY 8(f)-1, m = 16 (train.py:75)
 }
 MASK_EPOCHS = [10, 20, 30, 40]
 STAGE_EPOCH = {8: 0, 12: 10, 18: 20, 20: 30, -1: 40}
@@ -79,6 +79,19 @@ def cpu_baseline(args, variant, preset, img, patch, classes, w):
         net = R.RefVisionTransformerLAI(img_size=img, patch_size=patch, num_classes=classes, embed_dim=p['dim'],
                                         depth=depth, num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'],
                                         mask_epochs=me)
+    elif variant == 'performer_timm':
+        # train.py:147-165: a timm ViT whose attention modules are swapped for PerformerAttention (its forward takes no epoch)
+        class NoEpoch(torch.nn.Module):
+            def __init__(self, mod):
+                super().__init__()
+                self.mod = mod
+
+            def forward(self, x, epoch=None):
+                return self.mod(x)
+        net = R.RefVisionTransformerLAI(img_size=img, patch_size=patch, num_classes=classes, embed_dim=p['dim'],
+                                        depth=depth, num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'], mask_epochs=None)
+        for blk in net.blocks:
+            blk.attn = NoEpoch(R.RefPerformerAttention(p['dim'], num_heads=p['heads'], qkv_bias=True, n_orf=64))
     elif variant == 'disentangled_performer':
         tr = R.RefDisentangledPerformerTransformer(d_model=p['dim'], nhead=p['heads'], num_encoder_layers=depth,
                                                    dim_feedforward=p['mlp'], normalize_before=True, norf=16)
@@ -97,7 +110,7 @@ def cpu_baseline(args, variant, preset, img, patch, classes, w):
     Bc = args.cpu_batch
     x = torch.randn(Bc, 3, img, img)
     y = torch.randint(0, classes, (Bc,))
-    epoch = STAGE_EPOCH[w] if me is not None else None
+    epoch = STAGE_EPOCH[w] if me is not None else (0 if variant == 'performer_timm' else None)   # the LAI shell's forward wants one
     R.train_step(net, opt, x, y, epoch)           # warm-up
     t0 = time.perf_counter()
     n = 0
@@ -238,7 +251,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and not variant.startswith('performer'):   # no oracle model of config 5's timm shell
+        if world == 1 and not args.no_cpu_baseline and variant != 'performer':      # model.Performer has no oracle shell
             cpu = cpu_baseline(args, variant, preset, img, patch, classes, w)
         out = {
             'metric': 'train images/sec (node) ViT-B/16-224 LAI+Dis' if args.workload == 'dislai_b16'
