@@ -45,10 +45,7 @@ def test_eval_no_grad_with_dropout_modules(variant):
     with torch.no_grad():
         got = net(*args)
     assert not got.requires_grad and got.shape == (4, 10)
-    if variant == 'disperf':      # the KV contraction adds its four waves' partial sums through LDS atomics: order varies
-        assert (got - want.detach()).abs().max().item() <= 1e-5 * want.abs().max().item()
-    else:
-        assert torch.equal(got, want.detach())
+    assert torch.equal(got, want.detach())              # every forward kernel reduces in a fixed order
     with torch.no_grad():                               # batch of one: the reference squeezes it (model.py:62)
         one = net(*((img[:1],) + args[1:]))
     assert one.shape == (10,)

@@ -275,19 +275,24 @@ __global__ __launch_bounds__(256) void favor_kv_kernel(const FavorParams p) {
         }
         wave_lds_sync();
     }
-    // reduce the 4 waves: acc[dt][mt][r] = KV^T[d = 16dt+4g+r][feature 16mt+li]
+    // reduce the 4 waves, one after the other (a fixed order: the forward is bit-reproducible; LDS atomics would add
+    // in arrival order): acc[dt][mt][r] = KV^T[d = 16dt+4g+r][feature 16mt+li]
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
 #pragma unroll
-    for (int mt = 0; mt < MTC; ++mt) {
-        float s = ks[mt];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (g == 0) atomicAdd(&ksr[16 * mt + li], s);
+            for (int mt = 0; mt < MTC; ++mt) {
+                float s = ks[mt];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (g == 0) ksr[16 * mt + li] += s;
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
+                for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li], acc[dt][mt][r]);
+                    for (int r = 0; r < 4; ++r) red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li] += acc[dt][mt][r];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     T* KVT = reinterpret_cast<T*>(p.kvt) + ((long)b * p.H + h) * dh * p.mp;
     T* KV = reinterpret_cast<T*>(p.kv) + ((long)b * p.H + h) * p.mp * p.dhp;
     float* KS = p.ksum + ((long)b * p.H + h) * p.mp;
