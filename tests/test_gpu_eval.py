@@ -13,6 +13,12 @@ def _build(variant, dropout):
     from vit_amd.disentangled_transformer.disentangled_transformer import DisentangledTransformer
     from vit_amd.precision import set_compute_dtype
     torch.manual_seed(0)
+    if variant == 'lai':
+        from vit_amd.timm_classes.timm_locality_aware_transformer import VisionTransformerLAI
+        net = VisionTransformerLAI(img_size=32, patch_size=4, num_classes=10, embed_dim=128, depth=2, num_heads=4,
+                                   mlp_ratio=2.0, qkv_bias=True, drop_rate=dropout, attn_drop_rate=dropout,
+                                   mask_epochs=[10, 20, 30, 40]).cuda()
+        return set_compute_dtype(net, torch.float32)
     if variant == 'regular':
         tr = M.Transformer(d_model=128, dropout=dropout, nhead=4, dim_feedforward=256, num_encoder_layers=2,
                            normalize_before=True)
@@ -31,10 +37,10 @@ def _build(variant, dropout):
     return set_compute_dtype(net, torch.float32)
 
 
-@pytest.mark.parametrize('variant', ['regular', 'dis', 'dislai', 'disperf'])
+@pytest.mark.parametrize('variant', ['regular', 'dis', 'dislai', 'disperf', 'lai'])
 def test_eval_no_grad_with_dropout_modules(variant):
     img = torch.randn(4, 3, 32, 32, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
-    args = (img, 30) if variant == 'dislai' else (img,)
+    args = (img, 30) if variant in ('dislai', 'lai') else (img,)
     ref = _build(variant, 0.0)
     want = ref(*args)                                   # training mode, p = 0, autograd on
     net = _build(variant, 0.1)
@@ -48,6 +54,7 @@ def test_eval_no_grad_with_dropout_modules(variant):
     assert torch.equal(got, want.detach())              # every forward kernel reduces in a fixed order
     with torch.no_grad():                               # batch of one: the reference squeezes it (model.py:62)
         one = net(*((img[:1],) + args[1:]))
-    assert one.shape == (10,)
+    assert one.shape == ((1, 10) if variant == 'lai' else (10,))       # the timm shell keeps the batch dim
+    one = one.reshape(10)
     if variant != 'disperf':      # FAVOR+'s key stabiliser is the max over the WHOLE batch (dis :736): its outputs depend
         assert (one - want[0].detach()).abs().max().item() <= 1e-5 * want.abs().max().item()     # on the batch, upstream too
