@@ -77,14 +77,35 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunk = D >> 3;
-    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-        float v[NV][8];
+    const long stride = (long)gridDim.x * 4;
+    long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    // gamma / beta once per wave, and the next row's loads in flight while this one is reduced and stored
+    float g[NV][8], b[NV][8], v[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            load8<float>(g[i], gamma + c * 8);
+            load8<float>(b[i], beta + c * 8);
+            load8<T>(v[i], x + row * ldx + c * 8);
+        }
+    }
+    for (; row < rows; row += stride) {
+        float nx[NV][8];
+        const long nrow = row + stride;
+        if (nrow < rows) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nchunk) load8<T>(nx[i], x + nrow * ldx + c * 8);
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                load8<T>(v[i], x + row * ldx + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[i][e];
             }
@@ -107,17 +128,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                float g[8], b[8], o[8];
-                load8<float>(g, gamma + c * 8);
-                load8<float>(b, beta + c * 8);
+                float o[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
                 store8<T>(y + row * ldy + c * 8, o);
             }
         }
         if (lane == 0) {
             if (mean_out) mean_out[row] = mean;
             if (rstd_out) rstd_out[row] = rstd;
+        }
+        if (nrow < rows) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = nx[i][e];
         }
     }
 }
