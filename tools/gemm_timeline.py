@@ -1,7 +1,7 @@
 """Per-item timeline of the persistent 256-tile GEMM (build gemm256.hip with -DVITK_GEMM_STAMPS):
 main-loop and epilogue cycles of every item a workgroup walks, and the shader clock under load."""
 import sys, os
-os.environ['VITK_GEMM_DEBUG'] = '64'
+os.environ.setdefault('VITK_GEMM_DEBUG', '64')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vit_amd import _lib
@@ -9,8 +9,9 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_stamp
 from vit_amd import ops
 M = 128 * 197
 MP = M + 448
-for (name, m, n, k, ta, tb) in [('qkv NT', M, 3072, 1024, False, True), ('fc2 NT', M, 1024, 4096, False, True),
-                                ('dw fc1 TN', 4096, 1024, MP, True, False), ('dw proj TN', 1024, 1024, MP, True, False),
+for (name, m, n, k, ta, tb) in [('fc1 NT', M, 4096, 1024, False, True), ('proj NT', M, 1024, 1024, False, True),
+                                ('fc2 NT', M, 1024, 4096, False, True), ('dx qkv NT', MP, 1024, 3072, False, True),
+                                ('dw fc1 TN', 4096, 1024, M, True, False), ('dw proj TN', 1024, 1024, M, True, False),
                                 ('dw qkv TN', 3072, 1024, MP, True, False), ('sq4096 NT', 4096, 4096, 4096, False, True)]:
     a = (torch.randn(k, m, device='cuda') if ta else torch.randn(m, k, device='cuda')).bfloat16()
     b = (torch.randn(n, k, device='cuda') if tb else torch.randn(k, n, device='cuda')).bfloat16()
@@ -27,7 +28,7 @@ for (name, m, n, k, ta, tb) in [('qkv NT', M, 3072, 1024, False, True), ('fc2 NT
     t0 = s[:, :, 0].min().item()
     tend = s[:, :, 1:].max().item()
     print(f'{name}: event {us:.1f} us (cold, one call)', flush=True)
-    for blk in (0, 1, 100, 255):
+    for blk in (0, 8, 96, 248):
         row = s[blk, 0]
         items = []
         for r in range(10):
