@@ -91,6 +91,21 @@ int vitk_adamw(int rows, int cols, float* p, const float* g, float* m, float* v,
 int vitk_adamw_dyn(int rows, int cols, float* p, const float* g, float* m, float* v, double beta1,
                    double beta2, double eps, const float* dyn, void* shadow, long ld_shadow,
                    void* shadow_t, long ld_shadow_t, void* stream);
+/* optimizer.step() of train.py:549 for a whole parameter group in ONE launch (the multi-tensor pass SURVEY
+ * 8(f)-2 names).  desc: DEVICE memory, n + 1 records of vitk_adamw_desc_bytes() = 72 bytes, each 9 int64 words
+ * {p, g, m, v, shadow, shadow_t, ld_shadow | ld_shadow_t << 32, rows | cols << 32, tile0 | tiles_x << 32}
+ * (64 x 64 tiles: tiles_x = ceil(cols / 64), tile0 = running sum of tiles_x * ceil(rows / 64); record n holds
+ * tile0 = total_tiles only).  dyn as in vitk_adamw_dyn.  Per-element arithmetic identical to vitk_adamw. */
+int vitk_adamw_multi(int n, const void* desc, long total_tiles, double beta1, double beta2, double eps,
+                     const float* dyn, void* stream);
+int vitk_adamw_desc_bytes(void);
+/* dst[0..n) = {v0..v3}[0..n), n <= 4, written by a kernel from its ARGUMENTS: how the host hands dyn to a replayed
+ * graph without keeping a host buffer alive (no counterpart in the reference; plumbing of vitk_adamw_dyn/_multi). */
+int vitk_set_f32(float* dst, int n, float v0, float v1, float v2, float v3, void* stream);
+/* bytes (a multiple of 8, <= 1 MiB) from host memory to device memory THROUGH KERNEL ARGUMENTS, 2 KiB per launch:
+ * stream-ordered, legal inside a stream capture, and the host buffer is free again when the call returns.  No
+ * counterpart in the reference: how vitk_adamw_multi's descriptor table reaches the device. */
+int vitk_upload_args(void* dst, const void* src_host, size_t bytes, void* stream);
 
 /* Patch gather / scatter for Conv2d(kernel = stride = P): out[(b*nph+ph)*npw+pw][(c*P+py)*P+px] =
  * img[b][c][ph*P+py][pw*P+px]  (model.py:92-99: proj(x).flatten(2).transpose(1,2)). */

@@ -95,3 +95,18 @@ def test_only_rank0_writes(tmp_path):
     s.close()
     mp.spawn(_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ['rank0.pth']
+
+
+def test_loads_a_ddp_wrapped_reference_checkpoint(tmp_path):
+    """The reference saves the state_dict of the DDP- / DataParallel-wrapped model in its multi-GPU modes
+    (train.py:588 after :635 / :646): every key carries a 'module.' prefix."""
+    net = _tiny()
+    path = tmp_path / 'ddp.pth'
+    torch.save({'model': {'module.' + k: v for k, v in net.state_dict().items()}, 'epoch': 3}, path)
+    net2 = _tiny()
+    with torch.no_grad():
+        for p in net2.parameters():
+            p.mul_(0.0)
+    assert C.load_checkpoint(path, net2)[0] == 3
+    for p, q in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(p, q)

@@ -236,3 +236,32 @@ def test_headline_size_batch_independence_and_grad_sum():
         a, b = p.grad.detach().float(), full[n]
         l2 = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
         assert l2 < 3e-2, (n, l2)      # bf16 activations; fp32 accumulation in another order
+
+
+def test_ext_workspace_not_shared_between_layouts():
+    """Two (batch, tokens) layouts with the same padded row count (N = 17: B = 128 and a last partial batch of 127
+    both pad to 2240 rows) must not see each other's table-gradient rows in the backward scratch buffers."""
+    from vit_amd import functional as VF
+    from vit_amd.train import build_model, label_smoothing_ce
+    torch.manual_seed(0)
+    net = build_model('disentangled_lai_attention', 'S', img_size=16, patch_size=4, num_classes=10,
+                      mask_epochs=[10, 20, 30, 40], depth=2, dim=128, mlp=256, heads=4, dtype=torch.bfloat16)
+    xa = torch.randn(128, 3, 16, 16, device='cuda')
+    xb = torch.randn(127, 3, 16, 16, device='cuda')
+    ya = torch.randint(0, 10, (128,), device='cuda')
+    yb = torch.randint(0, 10, (127,), device='cuda')
+
+    def grads(x, y):
+        for p in net.parameters():
+            p.grad = None
+        label_smoothing_ce(net(x, 40), y).backward()
+        return {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    VF._ext_ws.clear()
+    alone = grads(xb, yb)                 # layout B on fresh buffers
+    VF._ext_ws.clear()
+    grads(xa, ya)                         # layout A leaves its table gradients behind
+    after = grads(xb, yb)
+    for n in alone:
+        scale = alone[n].abs().max().clamp_min(1e-12)
+        assert ((alone[n] - after[n]).abs().max() / scale).item() < 1e-3, n    # split-K atomics reorder fp32 sums; stale rows would be O(1)

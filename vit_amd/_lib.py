@@ -28,6 +28,10 @@ _SIGNATURES = {
                             c_vp, c_long, c_vp, c_long, c_vp, c_vp, c_vp, c_vp], c_int),
     'vitk_adamw_dyn': ([c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_double, c_vp,
                         c_vp, c_long, c_vp, c_long, c_vp], c_int),
+    'vitk_adamw_multi': ([c_int, c_vp, c_long, c_double, c_double, c_double, c_vp, c_vp], c_int),
+    'vitk_adamw_desc_bytes': ([], c_int),
+    'vitk_upload_args': ([c_vp, c_vp, ctypes.c_size_t, c_vp], c_int),
+    'vitk_set_f32': ([c_vp, c_int, c_float, c_float, c_float, c_float, c_vp], c_int),
     'vitk_colsum': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_vp], c_int),
     'vitk_cast': ([c_int, c_long, c_vp, c_vp, c_vp], c_int),
     'vitk_adamw': ([c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_double, c_double, c_double, c_int,

@@ -51,7 +51,12 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location='c
     for key in ('model', 'epoch'):
         if key not in ck:
             raise KeyError(f'{path}: not a checkpoint of this format (no {key!r})')
-    model.load_state_dict(ck['model'])
+    sd = ck['model']
+    if sd and all(k.startswith('module.') for k in sd):
+        # the reference saves model.state_dict() of the DDP- / DataParallel-wrapped model in its multi-GPU modes
+        # (train.py:588 after :635 / :646): every key then carries the wrapper's 'module.' prefix
+        sd = {k[len('module.'):]: v for k, v in sd.items()}
+    model.load_state_dict(sd)
     if optimizer is not None:
         if 'optimizer' not in ck:
             raise KeyError(f'{path}: no optimizer state')

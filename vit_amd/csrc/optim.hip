@@ -33,10 +33,9 @@ struct AdamWParams {
     const float* dyn;   // optional device scalars {decay, step_size, inv_bc2_sqrt}: a captured HIP graph replays with new ones
 };
 
-__global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
-    __shared__ __attribute__((aligned(16))) __bf16 tile[OPT_TILE * OPT_LD];   // [col][row]
+// One 64 x 64 tile of one parameter (tile origin r0, c0); ``tile`` = the workgroup's LDS staging of the transposed copy.
+__device__ __forceinline__ void adamw_tile(const AdamWParams& a, int r0, int c0, __bf16* tile) {
     const int t = threadIdx.x;
-    const int r0 = blockIdx.y * OPT_TILE, c0 = blockIdx.x * OPT_TILE;
     const int cg = t & 15, rr = t >> 4;
     const int c = c0 + 4 * cg;
     const float decay = a.dyn ? a.dyn[0] : a.decay;
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
             for (int e = 0; e < 4; ++e) tile[(4 * cg + e) * OPT_LD + rl] = (__bf16)pn[e];
         }
     }
-    if (!a.shadow_t) return;
+    if (!a.shadow_t) return;     // (uniform over the workgroup)
     __syncthreads();
     // transposed copy: row (c0 + cl) of shadow_t gets rows r0 .. r0+63 of this tile
     const int rg = t & 7;
@@ -114,6 +113,57 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
             for (int e = 0; e < 8 && r + e < a.rows; ++e) dst[e] = src[e];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[OPT_TILE * OPT_LD];   // [col][row]
+    adamw_tile(a, blockIdx.y * OPT_TILE, blockIdx.x * OPT_TILE, tile);
+}
+
+// Multi-tensor form: ONE launch updates every parameter of a group.  ``desc`` (device memory, written by the
+// host once per set of tensors) lists the parameters; tile ids run through them in order (desc[i].tile0 = the
+// first id of parameter i, desc[n].tile0 = the total).  Persistent workgroups walk the ids blockIdx.x,
+// + gridDim.x, ...: 148 launches of the per-parameter form (2.6 ms, 4.1 TB/s for the 306 M parameters of the
+// headline model: the small ones cannot fill the chip and every launch has its ramp) become one.
+struct AdamWDesc {       // 72 bytes; the host writes it as 9 int64 words (little endian: low int first)
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    __bf16* shadow;
+    __bf16* shadow_t;
+    int ld_shadow, ld_shadow_t;
+    int rows, cols;
+    int tile0, tiles_x;
+};
+static_assert(sizeof(AdamWDesc) == 72, "AdamWDesc layout");
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamWDesc* __restrict__ desc, int n, AdamWParams base) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[OPT_TILE * OPT_LD];
+    const int total = desc[n].tile0;
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+        int lo = 0, hi = n;                       // last i with desc[i].tile0 <= id
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (desc[mid].tile0 <= id) lo = mid;
+            else hi = mid;
+        }
+        const AdamWDesc d = desc[lo];
+        AdamWParams a = base;
+        a.p = d.p; a.g = d.g; a.m = d.m; a.v = d.v;
+        a.shadow = d.shadow; a.ld_shadow = d.ld_shadow;
+        a.shadow_t = d.shadow_t; a.ld_shadow_t = d.ld_shadow_t;
+        a.rows = d.rows; a.cols = d.cols;
+        const int local = id - d.tile0;
+        const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
+        adamw_tile(a, ty * OPT_TILE, tx * OPT_TILE, tile);
+        __syncthreads();                          // the LDS tile is reused by the next id
+    }
+}
+
+__global__ void set_f32_kernel(float* dst, int n, float v0, float v1, float v2, float v3) {
+    const float v[4] = {v0, v1, v2, v3};
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v[threadIdx.x];
 }
 
 }  // namespace vitk
@@ -175,3 +225,40 @@ extern "C" int vitk_adamw_dyn(int rows, int cols, float* p, const float* g, floa
     return adamw_impl(rows, cols, p, g, m, v, 0.0, beta1, beta2, eps, 0.0, 1, shadow, ld_shadow, shadow_t, ld_shadow_t,
                       dyn, stream);
 }
+
+// n <= 4 floats written to device memory from KERNEL ARGUMENTS (by value): the stream-ordered way to hand a captured
+// graph its per-replay scalars -- no host buffer has to stay untouched until the copy runs.
+extern "C" int vitk_set_f32(float* dst, int n, float v0, float v1, float v2, float v3, hipStream_t stream) {
+    VITK_CHECK_ARG(dst && n >= 1 && n <= 4, "vitk_set_f32: n must be 1..4");
+    hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(64), 0, stream, dst, n, v0, v1, v2, v3);
+    VITK_CHECK_LAUNCH("vitk_set_f32");
+    return VITK_OK;
+}
+
+// Multi-tensor AdamW: every parameter listed in ``desc`` in ONE launch.  desc = DEVICE memory, n + 1 records of
+// 9 int64 words {p, g, m, v, shadow, shadow_t, ld_shadow | ld_shadow_t << 32, rows | cols << 32,
+// tile0 | tiles_x << 32}: tiles are 64 x 64, tiles_x = ceil(cols / 64), tile0 = the running sum of
+// tiles_x * ceil(rows / 64) over the records before; record n carries only tile0 = total_tiles.  The three
+// step-dependent scalars come from device memory (dyn = {1 - lr wd, lr / (1 - b1^t), 1 / sqrt(1 - b2^t)}), as in
+// vitk_adamw_dyn.  Same per-element arithmetic as vitk_adamw.
+extern "C" int vitk_adamw_multi(int n, const void* desc, long total_tiles, double beta1, double beta2, double eps,
+                                const float* dyn, hipStream_t stream) {
+    VITK_CHECK_ARG(n >= 0 && total_tiles >= 0, "vitk_adamw_multi: negative count");
+    if (n == 0 || total_tiles == 0) return VITK_OK;
+    VITK_CHECK_ARG(desc && dyn, "vitk_adamw_multi: null table");
+    VITK_CHECK_ARG(total_tiles < (1L << 31), "vitk_adamw_multi: too many tiles");
+    AdamWParams a = {};
+    a.b1 = (float)beta1; a.b2 = (float)beta2;
+    a.omb1 = (float)(1.0 - beta1);
+    a.omb2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    a.dyn = dyn;
+    long grid = total_tiles < 4096 ? total_tiles : 4096;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)grid), dim3(256), 0, stream,
+                       reinterpret_cast<const AdamWDesc*>(desc), n, a);
+    VITK_CHECK_LAUNCH("vitk_adamw_multi");
+    return VITK_OK;
+}
+
+// Size in bytes of one descriptor record (the host checks its layout against it).
+extern "C" int vitk_adamw_desc_bytes(void) { return (int)sizeof(AdamWDesc); }

@@ -418,12 +418,14 @@ class PreLNBlockFn(torch.autograd.Function):
 _ext_ws = {}
 
 
-def _ext_workspace(tag, rows, cols, dtype, device):
+def _ext_workspace(tag, rows, cols, dtype, device, layout):
     """Backward scratch of the extended-row layout ([tokens + table rows, cols]), one per shape for the
     whole model: layers run one after the other on the stream, nothing here is saved or returned,
     and the rows past the tokens that must read as zero are zeroed ONCE (kernels only write the
-    token rows; the table-gradient rows are rewritten whole every layer)."""
-    key = (tag, rows, cols, dtype, device)
+    token rows; the table-gradient rows are rewritten whole every layer).  ``layout`` = (token rows,
+    table rows): two layouts with the same padded row count must not share a buffer -- the stale table
+    gradients of one would lie in the must-be-zero rows of the other."""
+    key = (tag, rows, cols, dtype, device, layout, torch.cuda.current_stream(device).cuda_stream)
     buf = _ext_ws.get(key)
     if buf is None:
         if len(_ext_ws) > 16:
@@ -520,7 +522,7 @@ class DisLayerFn(torch.autograd.Function):
         if dwout is s_wout:
             dwout = dwout.detach()
         dg1, dbe1, dbo = zp.take(D), zp.take(D), zp.take(D)
-        ds1_ext = _ext_workspace('ds1', ME, D, dt, x_ext.device) if band is not None else \
+        ds1_ext = _ext_workspace('ds1', ME, D, dt, x_ext.device, (M1, R)) if band is not None else \
             torch.empty(ME, D, device=x_ext.device, dtype=dt)
         ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
         dwo = _dw(ds1, attn, out=s_wo if s_wo is not None else zp.take(D, D))
@@ -529,7 +531,7 @@ class DisLayerFn(torch.autograd.Function):
         dattn = _dx(ds1, wo)
         tables = dtab = None
         if band is not None:
-            dqkv_ext = _ext_workspace('dqkv', ME, 3 * D, dt, x_ext.device)
+            dqkv_ext = _ext_workspace('dqkv', ME, 3 * D, dt, x_ext.device, (M1, R))
             tables = qkv_ext[M1:M1 + R, :2 * D]
             dtab = zp.take(R, 2 * D)
         else:
