@@ -208,6 +208,15 @@ int vitk_ce_smooth_fwd(int B, int C, const float* logits, long ld, const long lo
                        float* loss_rows, float* lse, float* loss, void* stream);
 int vitk_ce_smooth_bwd(int B, int C, const float* logits, long ld, const long long* target, float smoothing,
                        const float* lse, const float* gout, float* dlogits, long ld_d, void* stream);
+/* vitk_ce_smooth_fwd for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  Same kernels and results; the per-row partial
+ * losses live in a static device array of the library (256 KiB per GPU, held until the process ends) instead of a
+ * caller buffer, so the caller passes inputs and outputs only: lse [B], loss [1].  B <= vitk_ce_static_max_rows()
+ * (65536), larger B is refused with an error.  Calls that overlap in time on ONE GPU share the array and race;
+ * consecutive calls on a stream do not (each writes the rows it reads). */
+int vitk_ce_smooth_fwd_static(int B, int C, const float* logits, long ld, const long long* target, float smoothing,
+                              float* lse, float* loss, void* stream);
+int vitk_ce_static_max_rows(void);
 
 #ifdef __cplusplus
 }

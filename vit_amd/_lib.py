@@ -55,6 +55,8 @@ _SIGNATURES = {
     'vitk_favor_bwd': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_long, c_vp,
                         c_float, c_float, c_vp, c_vp, c_long, c_vp, c_vp, c_vp, c_long, c_vp, c_vp], c_int),
     'vitk_ce_smooth_fwd': ([c_int, c_int, c_vp, c_long, c_vp, c_float, c_vp, c_vp, c_vp, c_vp], c_int),
+    'vitk_ce_smooth_fwd_static': ([c_int, c_int, c_vp, c_long, c_vp, c_float, c_vp, c_vp, c_vp], c_int),
+    'vitk_ce_static_max_rows': ([], c_int),
     'vitk_ce_smooth_bwd': ([c_int, c_int, c_vp, c_long, c_vp, c_float, c_vp, c_vp, c_vp, c_long, c_vp], c_int),
     'vitk_favor_feature_pitch': ([c_int], c_int),
     'vitk_favor_pos_state_bytes': ([c_int, c_int], c_long),

@@ -5,6 +5,8 @@
 //     logp = log_softmax(x);  loss_row = (1 - s) * (-logp[target]) + s * (-mean_c logp);  loss = mean_rows
 // HBM-bound and tiny (B x C floats read twice): one wave per row, 4 rows per workgroup; the mean over rows is a
 // second one-wave kernel so that the summation order is fixed (no atomics).
+#include <mutex>
+
 #include "common.h"
 
 namespace vitk {
@@ -89,3 +91,62 @@ extern "C" int vitk_ce_smooth_bwd(int B, int C, const float* logits, long ld, co
     VITK_CHECK_LAUNCH("vitk_ce_smooth_bwd");
     return VITK_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// The forward for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc): same kernels as vitk_ce_smooth_fwd, but the per-row losses -- partial results that only the
+// one-wave mean kernel reads -- live in a file-scope device array instead of a caller / library buffer.  The caller
+// passes inputs and outputs only.
+//   * limit: B <= VITK_CE_STATIC_MAX_ROWS (65536 rows, 256 KiB of device memory per GPU the library runs on,
+//     held until the process ends);
+//   * every call on one GPU shares that GPU's array: calls that overlap in time on one GPU (two streams) race.
+//     Nothing in it has to start at zero: a call writes rows [0, B) before it reads them, rows past B are
+//     never read, so a smaller call after a larger one is unaffected by what the larger one left behind.
+// The array's NAME is a host-side stand-in, not a device address: its address on the current device is looked up
+// once per device with hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+constexpr int VITK_CE_STATIC_MAX_ROWS = 65536;
+static __device__ __align__(256) float scratch[VITK_CE_STATIC_MAX_ROWS];
+
+constexpr int VITK_MAX_DEVICES = 64;
+static float* g_scratch_ptr[VITK_MAX_DEVICES];     // per device: each GPU holds its own copy of the array
+static std::mutex g_scratch_mutex;
+
+// Address of this device's copy of `scratch` (looked up on the first call on that device, with it current).
+static int ce_static_scratch(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VITK_MAX_DEVICES) {
+        vitk_set_error("vitk_ce_smooth_fwd_static: no current device (or more than %d devices)", VITK_MAX_DEVICES);
+        return VITK_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        float* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || ptr == nullptr) {
+            vitk_set_error("vitk_ce_smooth_fwd_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return VITK_ERR_LAUNCH;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return VITK_OK;
+}
+
+extern "C" int vitk_ce_smooth_fwd_static(int B, int C, const float* logits, long ld, const long long* target,
+                                         float smoothing, float* lse, float* loss, hipStream_t stream) {
+    VITK_CHECK_ARG(B > 0 && C > 0, "vitk_ce_smooth_fwd_static: empty problem");
+    VITK_CHECK_ARG(B <= VITK_CE_STATIC_MAX_ROWS,
+                   "vitk_ce_smooth_fwd_static: B = %d rows exceeds the static scratch (%d rows); use vitk_ce_smooth_fwd", B,
+                   VITK_CE_STATIC_MAX_ROWS);
+    VITK_CHECK_ARG(logits && target && lse && loss && ld >= C, "vitk_ce_smooth_fwd_static: bad pointer / pitch");
+    VITK_CHECK_ARG(smoothing >= 0.f && smoothing < 1.f, "vitk_ce_smooth_fwd_static: smoothing must be in [0, 1)");
+    float* rows = nullptr;
+    const int st = ce_static_scratch(&rows);
+    if (st != VITK_OK) return st;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, B, C, logits, ld, target, smoothing, rows, lse);
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, stream, B, rows, loss);
+    VITK_CHECK_LAUNCH("vitk_ce_smooth_fwd_static");
+    return VITK_OK;
+}
+
+extern "C" int vitk_ce_static_max_rows(void) { return VITK_CE_STATIC_MAX_ROWS; }
