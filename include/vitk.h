@@ -134,10 +134,15 @@ int vitk_token_grads(int dtype, int B, int N, int D, const void* dx, float* dpos
  * pk / pq: the projected relative tables restricted to the 2N-1 reachable rows,
  *          row r <-> i - j = r - (N-1), element (r, h, d) at r * ld_p + h*dh + d; both NULL for
  *          plain / LAI attention.  score = Q_i.K_j + Q_i.pk[i-j] + K_j.pq[i-j].
- * band_w < 0: no mask.  out [B*N][ldo]; lse [B][H][N] fp32 (log-sum-exp, saved for backward). */
+ * band_w < 0: no mask.  out [B*N][ldo]; lse [B][H][N] fp32 (log-sum-exp, saved for backward).
+ * drop_p > 0: dropout on the probabilities after the softmax (attn_drop, timm_locality_aware_transformer.py:74;
+ *          self.dropout, disentangled_transformer.py:915): probability (b, h, i, j) is element
+ *          ((b*H + h)*N + i)*N + j of the counter-based keep stream (drop_seed, drop_offset) -- see vitk_dropout;
+ *          the backward regenerates the mask from the same three numbers. */
 int vitk_attn_fwd(int dtype, int B, int H, int N, int dh, const void* q, const void* k, const void* v,
                   long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
-                  void* out, long ldo, float* lse, void* stream);
+                  void* out, long ldo, float* lse, float drop_p, unsigned long long drop_seed,
+                  unsigned long long drop_offset, void* stream);
 
 /* Fused attention backward (autograd of the above): dq / dk / dv (T, same addressing with ld_d)
  * and, with tables, dpk / dpq fp32 [2N-1][ld_dp] ACCUMULATED into.  `workspace` must hold
@@ -147,7 +152,8 @@ int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void* q, const v
                   long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
                   const void* out, const void* dout, long ldo, const float* lse,
                   void* dq, void* dk, void* dv, long ld_d, float* dpk, float* dpq, long ld_dp,
-                  void* workspace, void* stream);
+                  void* workspace, float drop_p, unsigned long long drop_seed, unsigned long long drop_offset,
+                  void* stream);
 
 /* FAVOR+ (Performer) attention: feature maps + linear-attention contraction + normaliser, between
  * the qkv projection and the output projection.  Replaces PerformerAttention.forward :36-59 with
@@ -198,6 +204,17 @@ int vitk_favor_pos_attn_bwd(int dtype, int kind, int B, int H, int L, int dh, in
                             const void* v, long ld, const void* w, float ratio, float eps, const float* pq,
                             const float* pk, const void* out, const void* dout, long ldo, void* dq, void* dk,
                             void* dv, long ld_d, float* dnq, float* dnk, void* workspace, void* stream);
+
+/* nn.Dropout in training mode (disentangled_transformer.py:189,195,883; timm_locality_aware_transformer.py:78 and timm's
+ * Mlp / pos_drop; timm_vision_performer.py:61; model.py:201-203): y = x * keep / (1 - p) [+ res] on [rows, cols] rows.
+ * keep(r, c) = element r * cols + c of the counter-based stream (seed, offset): a 32-bit hash of (seed, offset, index)
+ * compared with p * 2^32 -- stateless, so the backward is the same call on dy (res NULL) and nothing is stored.  The
+ * reference draws its masks from torch's Philox stream, which a fused kernel cannot reproduce bit for bit: parity at
+ * p > 0 is defined with this mask handed to the oracle (vitk_dropout_mask, a test hook: out[i] = keep(i)). */
+int vitk_dropout(int dtype, int rows, int cols, const void* x, long ldx, const void* res, long ldr, void* y, long ldy,
+                 float p, unsigned long long seed, unsigned long long offset, void* stream);
+int vitk_dropout_mask(long n, float p, unsigned long long seed, unsigned long long offset, unsigned char* out,
+                      void* stream);
 
 /* Label-smoothing cross entropy, mean over the batch: criterion = LabelSmoothingCrossEntropy(smoothing)
  * (train.py:273, applied :541; timm 0.4.5 loss/cross_entropy.py): (1-s) * NLL + s * mean_c(-log p).

@@ -54,6 +54,21 @@ def lai_stage_width(epoch, mask_epochs):
 MASK_FILL = -1e9  # timm_locality_aware_transformer.py:70, disentangled_transformer.py:911
 
 
+# --------------------------------------------------------------------------- dropout
+# The reference's nn.Dropout sites draw from torch's generator; the oracle restates them as x * keep / (1 - p) with the
+# keep mask SUPPLIED: tests install DROPOUT = callable(p, shape) -> 0/1 tensor and hand it the very masks the HIP
+# kernels applied (vit_amd.ops.dropout_mask), in the order the reference reaches its sites.  None (default): p = 0.
+# Masks are indexed over batch-major tensors ([B, N, D] / [B, H, N, N] / [rows, D]), the layout of the kernels.
+DROPOUT = None
+
+
+def _drop(x, p):
+    if DROPOUT is None or p is None or p <= 0:
+        return x
+    keep = DROPOUT(float(p), tuple(x.shape))
+    return x * keep.to(dtype=x.dtype, device=x.device) / (1.0 - p)
+
+
 # --------------------------------------------------------------------------- A1
 class RefAttentionLAI(nn.Module):
     """timm_classes/timm_locality_aware_transformer.py:25-79."""
@@ -66,6 +81,7 @@ class RefAttentionLAI(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
         self.mask_epochs = mask_epochs
+        self.p_attn, self.p_proj = attn_drop, proj_drop
 
     def forward(self, x, epoch):
         B, N, C = x.shape
@@ -76,21 +92,22 @@ class RefAttentionLAI(nn.Module):
         w = lai_stage_width(epoch, self.mask_epochs)
         if w is not None:
             s = s.masked_fill(lai_band_mask(N, w).to(s.device) == 0, MASK_FILL)
-        p = s.softmax(dim=-1)
+        p = _drop(s.softmax(dim=-1), self.p_attn)                    # attn_drop (:74)
         y = torch.matmul(p, v).transpose(1, 2).reshape(B, N, C)
-        return self.proj(y)
+        return _drop(self.proj(y), self.p_proj)                       # proj_drop (:78)
 
 
 class RefMlp(nn.Module):
     """timm 0.4.5 ``Mlp``: fc1 -> GELU(erf) -> drop -> fc2 -> drop (parity unpinned)."""
 
-    def __init__(self, in_features, hidden_features):
+    def __init__(self, in_features, hidden_features, drop=0.):
         super().__init__()
         self.fc1 = nn.Linear(in_features, hidden_features)
         self.fc2 = nn.Linear(hidden_features, in_features)
+        self.p = drop
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return _drop(self.fc2(_drop(F.gelu(self.fc1(x)), self.p)), self.p)
 
 
 # --------------------------------------------------------------------------- A2
@@ -98,12 +115,13 @@ class RefBlockLAI(nn.Module):
     """timm_classes/timm_locality_aware_transformer.py:81-99 (pre-LN residual block)."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None,
-                 norm_layer=nn.LayerNorm, mask_epochs=None):
+                 norm_layer=nn.LayerNorm, mask_epochs=None, drop=0., attn_drop=0.):
         super().__init__()
         self.norm1 = norm_layer(dim)
-        self.attn = RefAttentionLAI(dim, num_heads, qkv_bias, qk_scale, mask_epochs=mask_epochs)
+        self.attn = RefAttentionLAI(dim, num_heads, qkv_bias, qk_scale, attn_drop=attn_drop, proj_drop=drop,
+                                    mask_epochs=mask_epochs)
         self.norm2 = norm_layer(dim)
-        self.mlp = RefMlp(dim, int(dim * mlp_ratio))
+        self.mlp = RefMlp(dim, int(dim * mlp_ratio), drop=drop)
 
     def forward(self, x, epoch):
         x = x + self.attn(self.norm1(x), epoch)
@@ -133,14 +151,17 @@ class RefVisionTransformerLAI(nn.Module):
     VisionTransformer shell (cls_token, pos_embed, blocks, norm eps 1e-6, head)."""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768,
-                 depth=12, num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, mask_epochs=None):
+                 depth=12, num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, mask_epochs=None,
+                 drop_rate=0., attn_drop_rate=0.):
         super().__init__()
+        self.p_pos = drop_rate
         norm_layer = partial(nn.LayerNorm, eps=1e-6)
         self.patch_embed = RefPatchEmbed(img_size, patch_size, in_chans, embed_dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
         self.blocks = nn.ModuleList([
-            RefBlockLAI(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer, mask_epochs)
+            RefBlockLAI(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer, mask_epochs,
+                        drop=drop_rate, attn_drop=attn_drop_rate)
             for _ in range(depth)])
         self.norm = norm_layer(embed_dim)
         self.head = nn.Linear(embed_dim, num_classes)
@@ -155,7 +176,7 @@ class RefVisionTransformerLAI(nn.Module):
     def forward(self, x, epoch):
         B = x.shape[0]
         x = self.patch_embed(x)
-        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed
+        x = _drop(torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed, self.p_pos)   # pos_drop (:139)
         for blk in self.blocks:
             x = blk(x, epoch)
         return self.head(self.norm(x)[:, 0])
@@ -194,6 +215,7 @@ class RefDisentangledSelfAttention(nn.Module):
                 self.pos_query_proj = nn.Linear(d_model, d_model)
         self.mask_epochs = mask_epochs
         self.lai = lai
+        self.p = dropout          # pos_dropout and self.dropout share it (:286,293); active only with DROPOUT installed
 
     def forward(self, q, k, value, relative_pos=None, rel_embeddings=None, query=None,
                 pos_embed=None, epoch=0):
@@ -211,7 +233,9 @@ class RefDisentangledSelfAttention(nn.Module):
         if self.relative_attention:
             S = self.pos_ebd_size
             lo, hi = max(S - (N - 1), 0), min(S + (N - 1), 2 * S - 1)
-            band = rel_embeddings[lo:hi + 1]                       # only reachable rows
+            # pos_dropout (:332,883) is drawn over the whole [2S, D] table upstream; only these rows are ever read, so
+            # the mask is drawn over them (same distribution, and the layout the kernels index)
+            band = _drop(rel_embeddings[lo:hi + 1], self.p)        # only reachable rows
             idx = (dis_delta_index(N, S) - lo).to(q.device)        # [N,N] into the band
             if 'c2p' in self.pos_att_type:
                 Pk = self.key_proj(band).view(-1, H, dh).transpose(0, 1)       # [H,R,dh]
@@ -227,7 +251,7 @@ class RefDisentangledSelfAttention(nn.Module):
         if w is not None:
             s = s.masked_fill(lai_band_mask(N, w).to(s.device) == 0, MASK_FILL)
         p = torch.softmax(s, -1)
-        ctx = torch.matmul(p, V).transpose(1, 2).reshape(B, N, D)
+        ctx = torch.matmul(_drop(p, self.p), V).transpose(1, 2).reshape(B, N, D)      # self.dropout (:343,915)
         return {'hidden_states': ctx, 'attention_probs': p, 'attention_logits': s}
 
 
@@ -252,12 +276,13 @@ class RefDisentangledEncoderLayer(nn.Module):
         self.dense_intermediate = nn.Linear(d_model, dim_feedforward)
         self.dense_out = nn.Linear(dim_feedforward, d_model)
         self.layer_norm_out = nn.LayerNorm(d_model)
+        self.p = dropout
 
     def forward(self, src, relative_pos=None, rel_embeddings=None, query=None, pos_embed=None, epoch=None):
         ctx = self.dis_attn(src, src, src, rel_embeddings=rel_embeddings,
                             epoch=0 if epoch is None else epoch)['hidden_states']
-        a = self.layer_norm_AttnOut(self.dense_AttnOut(ctx) + src)
-        return self.layer_norm_out(self.dense_out(F.gelu(self.dense_intermediate(a))) + a)
+        a = self.layer_norm_AttnOut(_drop(self.dense_AttnOut(ctx), self.p) + src)                    # dropout_AttnOut (:189)
+        return self.layer_norm_out(_drop(self.dense_out(F.gelu(self.dense_intermediate(a))), self.p) + a)   # dropout_out (:195)
 
 
 class RefDisentangledTransformer(nn.Module):
@@ -321,6 +346,11 @@ class RefTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.act = {'relu': F.relu, 'gelu': F.gelu}[activation]
         self.normalize_before = normalize_before
+        self.p = dropout
+
+    @staticmethod
+    def _dropnb(x, p):   # [N,B,D] tensor, mask indexed batch-major
+        return _drop(x.transpose(0, 1), p).transpose(0, 1)
 
     def _attn(self, x):  # [N,B,D]
         N, B, D = x.shape
@@ -328,16 +358,20 @@ class RefTransformerEncoderLayer(nn.Module):
         dh = D // H
         qkv = F.linear(x, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
         q, k, v = (t.reshape(N, B * H, dh).transpose(0, 1) for t in qkv.chunk(3, dim=-1))
-        p = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(dh), -1)
+        p = _drop(torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(dh), -1), self.p)   # MHA's dropout on the weights
         y = torch.bmm(p, v).transpose(0, 1).reshape(N, B, D)
-        return self.self_attn.out_proj(y)
+        return self._dropnb(self.self_attn.out_proj(y), self.p)                                  # dropout1 (:187,200)
+
+    def _ffn(self, x):
+        h = self._dropnb(self.act(self.linear1(x)), self.p)                                      # self.dropout (:189,202)
+        return self._dropnb(self.linear2(h), self.p)                                             # dropout2 (:190,203)
 
     def forward(self, src, pos=None):
         if self.normalize_before:
             src = src + self._attn(self.norm1(src))
-            return src + self.linear2(self.act(self.linear1(self.norm2(src))))
+            return src + self._ffn(self.norm2(src))
         src = self.norm1(src + self._attn(src))
-        return self.norm2(src + self.linear2(self.act(self.linear1(src))))
+        return self.norm2(src + self._ffn(src))
 
 
 class RefTransformer(nn.Module):
@@ -438,12 +472,13 @@ class RefPerformerAttention(nn.Module):
     """PerformerAttention (timm_classes/timm_vision_performer.py:10-65); ``w`` is an explicit
     attribute ([m, dh])."""
 
-    def __init__(self, dim, num_heads=8, qkv_bias=False, n_orf=64, kernel='softmax'):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, n_orf=64, kernel='softmax', attn_drop=0., proj_drop=0.):
         super().__init__()
         self.num_heads, self.m, self.kernel = num_heads, int(n_orf), kernel
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
         self.w = None
+        self.p_attn, self.p_proj = attn_drop, proj_drop
 
     def forward(self, x):
         B, N, C = x.shape
@@ -459,7 +494,8 @@ class RefPerformerAttention(nn.Module):
         else:
             kp = favor_relu_features(k, self.w, ratio)
             qp = favor_relu_features(q, self.w, ratio)
-        return self.proj(favor_linear_attention(qp, kp, v).flatten(-2))
+        x = _drop(favor_linear_attention(qp, kp, v).flatten(-2), self.p_attn)      # attn_drop on the OUTPUT (:61)
+        return _drop(self.proj(x), self.p_proj)                                    # proj_drop (:64)
 
 
 class RefDisentangledSelfAttentionPerformer(nn.Module):

@@ -1,7 +1,7 @@
 """The validation pass of the reference (train.py:556-579: model.eval(), torch.no_grad(), model(data[, epoch])) on
 modules built WITH dropout, as train.py builds them (--dropout 0.1): in eval mode dropout is the identity, so the
-kernels' p = 0 arithmetic is exact there; in training mode with p > 0 the modules must refuse rather than silently
-drop the dropout."""
+kernels' p = 0 arithmetic is exact there; in training mode with p > 0 the dropout sites are live (tests/test_gpu_dropout.py
+checks them against the oracle): the output must differ from the p = 0 one and change from call to call."""
 import pytest
 import torch
 
@@ -45,8 +45,10 @@ def test_eval_no_grad_with_dropout_modules(variant):
     want = ref(*args)                                   # training mode, p = 0, autograd on
     net = _build(variant, 0.1)
     net.load_state_dict(ref.state_dict())
-    with pytest.raises(NotImplementedError):
-        net(*args)                                      # training mode with p > 0: refused, not ignored
+    with torch.no_grad():
+        t1, t2 = net(*args), net(*args)                 # training mode with p > 0: dropout is applied, not ignored
+    assert not torch.equal(t1, want.detach()) and not torch.equal(t1, t2)
+    assert torch.isfinite(t1).all()
     net.eval()
     with torch.no_grad():
         got = net(*args)

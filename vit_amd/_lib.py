@@ -14,6 +14,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
 _lib = None
 
 c_int, c_long, c_float, c_double, c_vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+c_u64 = ctypes.c_ulonglong
 
 _SIGNATURES = {
     'vitk_version': ([], c_int),
@@ -43,11 +44,13 @@ _SIGNATURES = {
     'vitk_token_grads': ([c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp], c_int),
     'vitk_attn_fwd': ([c_int, c_int, c_int, c_int, c_int,
                        c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long,
-                       c_float, c_int, c_vp, c_long, c_vp, c_vp], c_int),
+                       c_float, c_int, c_vp, c_long, c_vp, c_float, c_u64, c_u64, c_vp], c_int),
     'vitk_attn_bwd': ([c_int, c_int, c_int, c_int, c_int,
                        c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long,
                        c_float, c_int, c_vp, c_vp, c_long, c_vp,
-                       c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_vp], c_int),
+                       c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_float, c_u64, c_u64, c_vp], c_int),
+    'vitk_dropout': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_long, c_vp, c_long, c_float, c_u64, c_u64, c_vp], c_int),
+    'vitk_dropout_mask': ([c_long, c_float, c_u64, c_u64, c_vp, c_vp], c_int),
     'vitk_attn_bwd_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),
     'vitk_favor_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),
     'vitk_favor_fwd': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_long, c_vp,

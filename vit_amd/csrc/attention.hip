@@ -27,6 +27,8 @@ struct AttnFwdParams {
     int B, H, N, dh;
     float scale;
     int w;                   // LAI half width, < 0: no mask
+    DropParams drop;         // dropout on the probabilities (disentangled_transformer.py:915, timm_locality_aware_transformer.py:74):
+                             // element (b, h, i, j) is element ((b*H + h)*N + i)*N + j of the stream; the normaliser keeps every term
 };
 
 template <typename T, int DKB, int KT, bool BIAS>
@@ -75,6 +77,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
         jlo = (jlo / KT) * KT;
     }
     const int qi = iw + li;  // this lane's query
+    const bool drop_on = p.drop.thresh != 0;
+    const uint64_t drow = ((uint64_t)(b * p.H + h) * (uint64_t)N + (uint64_t)min(qi, N - 1)) * (uint64_t)N;
 
     for (int j0 = jlo; j0 < jhi; j0 += KT) {
         __syncthreads();
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = exp2f(s[sidx][r] - mref);
-                s[sidx][r] = pv;
                 psum += pv;
+                s[sidx][r] = drop_on ? pv * drop_mul(p.drop, drow + (uint64_t)min(j0 + 16 * sidx + 4 * g + r, N - 1)) : pv;
             }
         lsum = lsum * alpha + psum;
         m2 = mn;
@@ -224,6 +228,7 @@ struct BandParams {
     float scale;
     int w;
     __bf16* ds_ws;
+    DropParams drop;
 };
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
 void band_launch(const BandParams& p, bool backward, hipStream_t st);
@@ -235,7 +240,9 @@ static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
 
 extern "C" int vitk_attn_fwd(int dtype, int B, int H, int N, int dh, const void* q, const void* k, const void* v,
                              long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
-                             void* out, long ldo, float* lse, hipStream_t stream) {
+                             void* out, long ldo, float* lse, float drop_p, unsigned long long drop_seed,
+                             unsigned long long drop_offset, hipStream_t stream) {
+    VITK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "vitk_attn_fwd: dropout p must be in [0, 1)");
     VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "vitk_attn_fwd: bad dtype");
     VITK_CHECK_ARG(B > 0 && H > 0 && N > 0, "vitk_attn_fwd: empty problem");
     const int esz = dtype == VITK_BF16 ? 2 : 4;
@@ -255,6 +262,7 @@ extern "C" int vitk_attn_fwd(int dtype, int B, int H, int N, int dh, const void*
         bp.out = out; bp.ldo = ldo; bp.lse = lse;
         bp.B = B; bp.H = H; bp.N = N; bp.dh = dh;
         bp.scale = scale; bp.w = band_w;
+        bp.drop = vitk_drop_params(drop_p, drop_seed, drop_offset);
         band_launch(bp, false, stream);
         VITK_CHECK_LAUNCH("vitk_attn_fwd");
         return VITK_OK;
@@ -265,6 +273,7 @@ extern "C" int vitk_attn_fwd(int dtype, int B, int H, int N, int dh, const void*
     p.out = out; p.ldo = ldo; p.lse = lse;
     p.B = B; p.H = H; p.N = N; p.dh = dh;
     p.scale = scale; p.w = band_w;
+    p.drop = vitk_drop_params(drop_p, drop_seed, drop_offset);
     if (dtype == VITK_BF16) attn_fwd_dispatch<__bf16, 64>(p, stream);
     else attn_fwd_dispatch<float, 32>(p, stream);
     VITK_CHECK_LAUNCH("vitk_attn_fwd");

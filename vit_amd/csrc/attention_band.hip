@@ -56,6 +56,7 @@ struct BandParams {
     float scale;
     int w;
     __bf16* ds_ws;          // backward with the bias: dS tiles for the table-gradient kernel (attention_bwd.hip)
+    DropParams drop;        // dropout on the probabilities, element ((b*H + h)*N + i)*N + j of the stream (attention.hip)
 };
 
 template <int DKB, bool BIAS> struct BandCfg {
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const B
 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
+    const bool drop_on = p.drop.thresh != 0;
+    const uint64_t dhead = (uint64_t)(b * p.H + h) * (uint64_t)N;
     // per-tile state of the (at most BAND_FWD_TPW) query tiles this wave owns
     Frag<T> qf[BAND_FWD_TPW][DKB];
     float m2[BAND_FWD_TPW], lsum[BAND_FWD_TPW];
@@ -200,8 +203,10 @@ __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const B
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = exp2f(sc[u][r] - mref);
-                        sc[u][r] = pv;
                         psum += pv;
+                        sc[u][r] = drop_on ? pv * drop_mul(p.drop, (dhead + (uint64_t)min(qi, N - 1)) * (uint64_t)N +
+                                                                       (uint64_t)min(16 * (ka + u) + 4 * g + r, N - 1))
+                                           : pv;
                     }
                 lsum[s] = lsum[s] * alpha + psum;
                 m2[s] = mn;
@@ -281,6 +286,8 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
+    const bool drop_on = p.drop.thresh != 0;
+    const uint64_t dhead = (uint64_t)(b * p.H + h) * (uint64_t)N;
 
     stage_rows<T, DKB>(Qs, Q, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
     // dO rows go to LDS and, on the way, delta_i = dO_i . O_i is formed (the CPR lanes of a row
@@ -364,8 +371,10 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                                 const int qi = qi0 + 4 * g + r, kj = kj0 + li;
                                 const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
                                 const float pe = ok ? exp2f(raw[r] * sc2 - lse2s[qi]) : 0.f;
-                                pv[r] = pe;
-                                dsv[r] = pe * (dp[r] - dls[qi]) * p.scale;
+                                // dropout: dV sees the dropped probabilities, dP = (dO V^T) * keep / (1 - p); delta is unchanged
+                                const float dm = (drop_on && ok) ? drop_mul(p.drop, (dhead + (uint64_t)qi) * (uint64_t)N + (uint64_t)kj) : 1.f;
+                                pv[r] = pe * dm;
+                                dsv[r] = pe * (dp[r] * dm - dls[qi]) * p.scale;
                             }
                             // the dS tile is kept for pass 2 and for the table-gradient kernel:
                             // entry (b, h, c + cmax, kt), lane l holds dS[4 (l >> 4) + r][l & 15]

@@ -59,6 +59,7 @@ struct AttnBwdParams {
     int w;
     int bgroup;         // rel kernel: batches per wave
     const __bf16* ds_ws; // whole-head path: dS tiles written by attn_bwd_band_kernel (else null)
+    DropParams drop;     // dropout on the probabilities (attention.hip)
 };
 
 __device__ __forceinline__ void frag_set(Frag<__bf16>& f, int e, float v) { f.v[e] = (__bf16)v; }
@@ -256,8 +257,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
                             const int qi = i0 + qr, kj = kj0 + li;
                             const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
                             const float pe = ok ? exp2f(raw[r] * sc2 - lse2s[qr]) : 0.f;
-                            pv[r] = pe;
-                            dsv[r] = pe * (dp[r] - dls[qr]) * p.scale;
+                            const float dm = (p.drop.thresh != 0 && ok)
+                                                 ? drop_mul(p.drop, ((uint64_t)(b * p.H + h) * (uint64_t)N + (uint64_t)qi) * (uint64_t)N + (uint64_t)kj)
+                                                 : 1.f;
+                            pv[r] = pe * dm;
+                            dsv[r] = pe * (dp[r] * dm - dls[qr]) * p.scale;
                         }
                     }
                     pt[qt][kt] = pv;
@@ -565,7 +569,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_rel_kernel(const AttnBwdParam
                         const int qi = qi0 + 4 * g + r, kj = kj0 + li;
                         const bool ok = qi < N && kj < N && (p.w < 0 || abs(qi - kj) <= p.w);
                         const float pe = ok ? exp2f(raw[r] * sc2 - lse2[u][r]) : 0.f;
-                        dsv[r] = pe * (dp[r] - dl[u][r]) * p.scale;
+                        const float dm = (p.drop.thresh != 0 && ok)
+                                             ? drop_mul(p.drop, ((uint64_t)(b * p.H + h) * (uint64_t)N + (uint64_t)qi) * (uint64_t)N + (uint64_t)kj)
+                                             : 1.f;
+                        dsv[r] = pe * (dp[r] * dm - dl[u][r]) * p.scale;
                     }
                 }
                 if (PADDED) {
@@ -903,6 +910,7 @@ struct BandParams {
     float scale;
     int w;
     __bf16* ds_ws;
+    DropParams drop;
 };
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
 void band_launch(const BandParams& p, bool backward, hipStream_t st);
@@ -933,8 +941,10 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
                              long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
                              const void* out, const void* dout, long ldo, const float* lse, void* dq, void* dk,
                              void* dv, long ld_d, float* dpk, float* dpq, long ld_dp, void* workspace,
+                             float drop_p, unsigned long long drop_seed, unsigned long long drop_offset,
                              hipStream_t stream) {
     VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "vitk_attn_bwd: bad dtype");
+    VITK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "vitk_attn_bwd: dropout p must be in [0, 1)");
     VITK_CHECK_ARG(B > 0 && H > 0 && N > 0, "vitk_attn_bwd: empty problem");
     const int esz = dtype == VITK_BF16 ? 2 : 4;
     VITK_CHECK_ARG(dh > 0 && dh <= 128 && (dh * esz) % 16 == 0, "vitk_attn_bwd: head dim %d unsupported", dh);
@@ -961,6 +971,7 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
     p.dpk = dpk; p.dpq = dpq; p.ld_dp = ld_dp;
     p.B = B; p.H = H; p.N = N; p.dh = dh;
     p.scale = scale; p.w = band_w;
+    p.drop = vitk_drop_params(drop_p, drop_seed, drop_offset);
     // batches per wave in the table-gradient kernel: enough waves to fill the chip (the kernel is
     // LDS-limited to ~8 waves per CU), few atomic flushes (one per wave)
     const int NT = (N + 15) / 16;
@@ -988,6 +999,7 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
         bp.dq = dq; bp.dk = dk; bp.dv = dv; bp.ld_d = ld_d;
         bp.B = B; bp.H = H; bp.N = N; bp.dh = dh;
         bp.scale = scale; bp.w = band_w;
+        bp.drop = p.drop;
         // pass 1 leaves its dS tiles behind delta: for pass 2 and for the table-gradient kernel
         bp.ds_ws = reinterpret_cast<__bf16*>(p.delta + ((long)B * H * N + 63) / 64 * 64);
         p.ds_ws = bp.ds_ws;

@@ -133,6 +133,33 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     return fmaf(0.5f, erfv, 0.5f) + x * (0.39894228040143267794f * e);
 }
 
+// ---------------------------------------------------------------------------------------- dropout
+// Counter-based keep mask: element `idx` of dropout stream (seed, offset) is kept iff a 32-bit hash of
+// (seed, offset, idx) is >= thresh = round(p * 2^32).  Stateless, so a backward kernel regenerates the mask
+// of its forward from the same three numbers and nothing is stored (the reference's nn.Dropout draws from
+// torch's Philox stream, which a fused kernel cannot reproduce bit for bit: parity at p > 0 is checked with
+// this mask exported -- vitk_dropout_mask -- and fed to the oracle).  Two rounds of the lowbias32 mixer.
+struct DropParams {
+    uint32_t seed_lo, seed_hi, off_lo, off_hi;
+    uint32_t thresh;     // 0: dropout off
+    float scale;         // 1 / (1 - p)
+};
+__device__ __forceinline__ uint32_t drop_mix(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool drop_keep(const DropParams& d, uint64_t idx) {
+    uint32_t x = drop_mix((uint32_t)idx * 0x9E3779B1u + d.seed_lo);
+    x = drop_mix(x + (uint32_t)(idx >> 32) * 0x85EBCA77u + d.seed_hi + d.off_lo * 0xC2B2AE3Du + d.off_hi * 0x27D4EB2Fu);
+    return x >= d.thresh;
+}
+// multiplier of a value under dropout: 0 or 1 / (1 - p)
+__device__ __forceinline__ float drop_mul(const DropParams& d, uint64_t idx) { return drop_keep(d, idx) ? d.scale : 0.f; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -161,6 +188,17 @@ extern "C" void vitk_set_error(const char* fmt, ...);
             return VITK_ERR_ARG;         \
         }                                \
     } while (0)
+
+// host side of DropParams: p in [0, 1)
+static inline vitk::DropParams vitk_drop_params(float p, unsigned long long seed, unsigned long long offset) {
+    vitk::DropParams d;
+    d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
+    d.off_lo = (uint32_t)offset; d.off_hi = (uint32_t)(offset >> 32);
+    double t = (double)p * 4294967296.0;
+    d.thresh = p <= 0.f ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)(t + 0.5));
+    d.scale = p <= 0.f ? 1.f : 1.f / (1.f - p);
+    return d;
+}
 
 // Zero-fill as a kernel of the library's own (runtime.hip) instead of hipMemsetAsync: an ordinary kernel node
 // when the stream is being captured into a HIP graph.  rows x row_bytes with a row pitch (pitch == row_bytes: flat).

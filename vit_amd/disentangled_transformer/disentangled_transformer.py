@@ -23,6 +23,7 @@ import torch.nn as nn
 from .. import functional as VF
 from ..precision import ComputeDtypeMixin
 from ..timm_classes.timm_locality_aware_transformer import _check_p0, get_attn_mask, lai_stage_width  # noqa: F401
+from .. import dropout as VD
 from ..timm_classes.timm_vision_performer import gaussian_orthogonal_random_matrix, orthogonal_matrix_chunk
 
 _band_idx_cache = {}
@@ -91,7 +92,10 @@ class DisentangledSelfAttention(ComputeDtypeMixin, nn.Module):
         The probabilities / logits the reference also returns are discarded by its only caller
         (reference :222) and are never materialised here.  ``relative_pos`` must be the default
         i - j grid (it is regenerated from indices in-kernel)."""
-        _check_p0(self, self.dropout.p, self.pos_dropout.p if self.relative_attention else 0.)
+        # dropout (training): pos_dropout on the relative rows (reference :332,883), self.dropout on the probabilities
+        # (:343,915) -- in that order, one stream each (vit_amd.dropout)
+        p_pos = self.pos_dropout.p if (self.training and self.relative_attention) else 0.
+        p_attn = self.dropout.p if self.training else 0.
         if relative_pos is not None and relative_pos.dim() not in (2, 3, 4):
             raise ValueError(f'Relative postion ids must be of dim 2 or 3 or 4. {relative_pos.dim()}')
         if query is not None:
@@ -102,12 +106,14 @@ class DisentangledSelfAttention(ComputeDtypeMixin, nn.Module):
         dt = self.compute_dtype
         H = self.num_attention_heads
         band = self.band_for(rel_embeddings, N, dt)
+        if band is not None and p_pos > 0:
+            band = VF.dropout(band, p_pos)
         w = self._width(epoch)
         qp, kp, vp = self.query_proj, self.key_proj, self.value_proj
         if q is k and k is value:
             x2 = q.reshape(B * N, D).to(dt)
             ctx = VF.DisAttentionFn.apply(x2, band, qp.weight, qp.bias, kp.weight, kp.bias, vp.weight, vp.bias,
-                                          (B, N, H, self.scale(), w))
+                                          (B, N, H, self.scale(), w, VD.next_stream(p_attn)))
         else:
             r2 = lambda t: t.reshape(B * N, D).to(dt)
             qkv = torch.cat([VF.linear(r2(q), qp.weight, qp.bias), VF.linear(r2(k), kp.weight, kp.bias),
@@ -115,7 +121,7 @@ class DisentangledSelfAttention(ComputeDtypeMixin, nn.Module):
             tables = None
             if band is not None:
                 tables = torch.cat([VF.linear(band, qp.weight, qp.bias), VF.linear(band, kp.weight, kp.bias)], dim=1)
-            ctx = VF.attention(qkv, tables, B, N, H, D // H, self.scale(), w)
+            ctx = VF.attention(qkv, tables, B, N, H, D // H, self.scale(), w, p_drop=p_attn)
         return {'hidden_states': ctx.view(B, N, D).to(q.dtype), 'attention_probs': None, 'attention_logits': None}
 
 
@@ -181,7 +187,6 @@ class DisentangledSelfAttentionPerformer(ComputeDtypeMixin, nn.Module):
 
     def attend2d(self, x2, pos2, B, N):
         """x2 [B*N, D], pos2 [N, D] (pos_embed rows), compute dtype -> context [B*N, D]."""
-        _check_p0(self, self.dropout.p)
         if pos2 is None:
             raise ValueError('DisentangledSelfAttentionPerformer needs pos_embed (reference :614)')
         if pos2.shape != (N, x2.shape[1]):
@@ -190,8 +195,11 @@ class DisentangledSelfAttentionPerformer(ComputeDtypeMixin, nn.Module):
             self.w = gaussian_orthogonal_random_matrix(self.m, self.head_dim, device=x2.device)
         qkv = VF.fused_linear(x2, self.query_proj, self.key_proj, self.value_proj)
         posqk = VF.fused_linear(pos2, self.pos_query_proj, self.pos_key_proj)
-        return VF.favor_pos_attention(qkv, posqk, self.w.to(x2.device), B, N, self.num_attention_heads,
-                                      self.attention_head_size, self.kernel, self.ratio())
+        ctx = VF.favor_pos_attention(qkv, posqk, self.w.to(x2.device), B, N, self.num_attention_heads,
+                                     self.attention_head_size, self.kernel, self.ratio())
+        if self.training and self.dropout.p > 0:       # context_layer = self.dropout(context_layer) (reference :604)
+            ctx = VF.dropout(ctx, self.dropout.p)
+        return ctx
 
     def forward(self, q, k, value, relative_pos=None, rel_embeddings=None, query=None, pos_embed=None):
         """pos_embed: [N, 1, D] as the encoder hands it down (reference :69,614).  relative_pos /
@@ -243,21 +251,51 @@ class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
         """The layer with FAVOR+ attention (reference :200-246 with dis_attn = the Performer variant): post-LN,
         residuals in the GEMM epilogues."""
         a = self.dis_attn
-        _check_p0(self, self.dropout_AttnOut.p, self.dropout_out.p)
         ctx = a.attend2d(x2, pos2, B, N)
+        return self._post_attention(ctx, x2)
+
+    def _drop_ps(self):
+        """(dropout_AttnOut.p, dropout_out.p) in training mode, else zeros."""
+        return (self.dropout_AttnOut.p, self.dropout_out.p) if self.training else (0., 0.)
+
+    def _post_attention(self, ctx, x2):
+        """forward_self_output / forward_intermediate / forward_output (reference :183-198) as separate autograd nodes:
+        LN(dropout(dense_AttnOut(ctx)) + x), then LN(dropout(dense_out(GELU(dense_intermediate(a)))) + a)."""
+        p1, p2 = self._drop_ps()
         n1, n2 = self.layer_norm_AttnOut, self.layer_norm_out
-        h = VF.layer_norm(VF.linear_res(ctx, self.dense_AttnOut.weight, self.dense_AttnOut.bias, x2),
-                          n1.weight, n1.bias, n1.eps)
+        if p1 > 0:
+            s1 = VF.dropout(VF.linear(ctx, self.dense_AttnOut.weight, self.dense_AttnOut.bias), p1, res=x2)
+        else:
+            s1 = VF.linear_res(ctx, self.dense_AttnOut.weight, self.dense_AttnOut.bias, x2)
+        h = VF.layer_norm(s1, n1.weight, n1.bias, n1.eps)
         y = VF.mlp(h, self.dense_intermediate.weight, self.dense_intermediate.bias, self.dense_out.weight,
-                   self.dense_out.bias, 'gelu', add_input=True)
+                   self.dense_out.bias, 'gelu', add_input=True, p_out=p2)
         return VF.layer_norm(y, n2.weight, n2.bias, n2.eps)
+
+    def dropout_active(self):
+        a = self.dis_attn
+        ps = [a.dropout.p, self.dropout_AttnOut.p, self.dropout_out.p]
+        if getattr(a, 'relative_attention', False) and hasattr(a, 'pos_dropout'):
+            ps.append(a.pos_dropout.p)
+        return self.training and any(p > 0 for p in ps)
 
     def forward2d(self, x2, band, B, N, epoch, x_ext=False):
         """x2 [B*N, D] and band [2N-1, D] (or None) in compute dtype -> [B*N, D]; one autograd node.
         ``x_ext``: x2 is the output of the previous layer's forward2d with the same band (its buffer
         already has the rows the relative table rides in: functional.DisLayerFn)."""
         a = self.dis_attn
-        _check_p0(self, a.dropout.p, self.dropout_AttnOut.p, self.dropout_out.p)
+        if self.dropout_active():
+            # training with dropout (the reference default, train.py:79): the layer as separate autograd nodes with the
+            # dropout sites of the reference in its order -- table rows, probabilities, attention output, block output
+            if x_ext:
+                raise ValueError('DisentangledEncoderLayer: the extended-row layout is not used with dropout')
+            p_pos = a.pos_dropout.p if a.relative_attention else 0.
+            bd = VF.dropout(band, p_pos) if (band is not None and p_pos > 0) else band
+            q, k, v = a.query_proj, a.key_proj, a.value_proj
+            ctx = VF.DisAttentionFn.apply(x2, bd, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
+                                          (B, N, a.num_attention_heads, a.scale(),
+                                           a._width(0 if epoch is None else epoch), VD.next_stream(a.dropout.p)))
+            return self._post_attention(ctx, x2)
         if self.layer_norm_AttnOut.eps != self.layer_norm_out.eps:
             raise NotImplementedError('DisentangledEncoderLayer: the two LayerNorms must share eps')
         cfg = (B, N, a.num_attention_heads, self.layer_norm_out.eps, a.scale(), a._width(0 if epoch is None else epoch),
@@ -336,7 +374,7 @@ class DisentangledEncoder(ComputeDtypeMixin, nn.Module):
         for i, layer in enumerate(self.layers):
             if band is None:
                 band = layer.dis_attn.band_for(rel, N, dt)   # identical for every (cloned) layer
-            x2 = layer.forward2d(x2, band, B, N, epoch, x_ext=i > 0)
+            x2 = layer.forward2d(x2, band, B, N, epoch, x_ext=i > 0 and not layer.dropout_active())
         return x2
 
     def forward(self, src, pos=None, epoch=None):

@@ -14,7 +14,8 @@ import weakref
 import torch
 
 from . import ops
-from .ops import ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU
+from . import dropout as VD
+from .ops import ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU, NO_DROP
 
 _shadow = {}          # key -> (versions, copy, weakrefs, transposed)
 _shadow_index = {}    # id(param) -> keys of the cached copies it is part of
@@ -271,8 +272,9 @@ def linear_res(x2d, weight, bias, res):
 
 
 # --------------------------------------------------------------------------- attention core
-def _attn_fwd(qkv, B, N, H, dh, tables, scale, w):
-    """qkv [B*N, 3D] (q | k | v).  tables: None or [2N-1, 2D] (Pq | Pk)."""
+def _attn_fwd(qkv, B, N, H, dh, tables, scale, w, drop=NO_DROP):
+    """qkv [B*N, 3D] (q | k | v).  tables: None or [2N-1, 2D] (Pq | Pk).  drop: (p, seed, offset) of the dropout on
+    the probabilities."""
     D = H * dh
     ld = qkv.stride(0)
     q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
@@ -281,10 +283,10 @@ def _attn_fwd(qkv, B, N, H, dh, tables, scale, w):
     if tables is not None:
         pq, pk = tables[:, :D], tables[:, D:]
         ld_p = tables.stride(0)
-    return ops.attn_fwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w)
+    return ops.attn_fwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w, drop=drop)
 
 
-def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None, dqkv=None):
+def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None, dqkv=None, drop=NO_DROP):
     """Returns dqkv [B*N, 3D] and (for tables) fp32 dtables [2N-1, 2D] (dPq | dPk); ``dtab``: a
     zeroed buffer to accumulate into."""
     D = H * dh
@@ -304,7 +306,7 @@ def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None, dqk
             dtab = torch.zeros(2 * N - 1, 2 * D, device=qkv.device, dtype=torch.float32)
         dpq, dpk = dtab[:, :D], dtab[:, D:]
     ops.attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w, out, dout, lse,
-                 dq, dk, dv, 3 * D, dpk, dpq, ld_dp=2 * D)
+                 dq, dk, dv, 3 * D, dpk, dpq, ld_dp=2 * D, drop=drop)
     return dqkv, dtab
 
 
@@ -312,24 +314,50 @@ class AttentionFn(torch.autograd.Function):
     """Fused attention on a packed qkv buffer: softmax(scale * (QK^T [+ c2p + p2c]) | LAI band) V."""
 
     @staticmethod
-    def forward(ctx, qkv, tables, B, N, H, dh, scale, w):
-        out, lse = _attn_fwd(qkv, B, N, H, dh, tables, scale, w)
+    def forward(ctx, qkv, tables, B, N, H, dh, scale, w, drop=NO_DROP):
+        out, lse = _attn_fwd(qkv, B, N, H, dh, tables, scale, w, drop)
         ctx.save_for_backward(qkv, tables, out, lse)
-        ctx.cfg = (B, N, H, dh, scale, w)
+        ctx.cfg = (B, N, H, dh, scale, w, drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, tables, out, lse = ctx.saved_tensors
-        B, N, H, dh, scale, w = ctx.cfg
-        dqkv, dtab = _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout.contiguous(), lse)
+        B, N, H, dh, scale, w, drop = ctx.cfg
+        dqkv, dtab = _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout.contiguous(), lse, drop=drop)
         if dtab is not None:
             dtab = dtab.to(tables.dtype)
-        return dqkv, dtab, None, None, None, None, None, None
+        return dqkv, dtab, None, None, None, None, None, None, None
 
 
-def attention(qkv, tables, B, N, H, dh, scale, w):
-    return AttentionFn.apply(qkv, tables, B, N, H, dh, scale, w)
+def attention(qkv, tables, B, N, H, dh, scale, w, p_drop=0.0):
+    """p_drop: dropout on the probabilities (a fresh stream is drawn per call when > 0)."""
+    return AttentionFn.apply(qkv, tables, B, N, H, dh, scale, w, VD.next_stream(p_drop))
+
+
+# --------------------------------------------------------------------------- dropout
+class DropoutFn(torch.autograd.Function):
+    """y = x * keep / (1 - p) [+ res]: nn.Dropout (training) with the residual add that follows it folded in.  The mask
+    is a function of (seed, offset, element index): the backward regenerates it, nothing is saved."""
+
+    @staticmethod
+    def forward(ctx, x, drop, res):
+        ctx.drop = drop
+        ctx.has_res = res is not None
+        return ops.dropout(x, drop, res=res)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return ops.dropout(dy, ctx.drop), None, (dy if ctx.has_res else None)
+
+
+def dropout(x2d, p, res=None):
+    """Training-mode dropout of a 2-D row view (+ res); p == 0: identity (+ res).  Draws one stream (vit_amd.dropout)."""
+    drop = VD.next_stream(p)
+    if drop[0] == 0.0:
+        return x2d if res is None else x2d + res
+    return DropoutFn.apply(x2d.contiguous(), drop, res)
 
 
 # --------------------------------------------------------------------------- fused encoder blocks
@@ -556,14 +584,15 @@ class DisAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, band, wq, bq, wk, bk, wv, bv, cfg):
-        B, N, H, scale, w = cfg
+        B, N, H, scale, w = cfg[:5]
+        drop = cfg[5] if len(cfg) > 5 else NO_DROP
         D = x.shape[1]
         dt = x.dtype
         wqkv = shadow((wq, wk, wv), dt)
         bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
         qkv = ops.gemm(x, wqkv, bias=bqkv)
         tables = ops.gemm(band, wqkv[:2 * D], bias=bqkv[:2 * D]) if band is not None else None
-        attn, lse = _attn_fwd(qkv, B, N, H, D // H, tables, scale, w)
+        attn, lse = _attn_fwd(qkv, B, N, H, D // H, tables, scale, w, drop)
         ctx.save_for_backward(x, band, wq, wk, wv, qkv, tables, attn, lse)
         ctx.cfg = cfg
         return attn
@@ -571,10 +600,11 @@ class DisAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dattn):
         x, band, wq, wk, wv, qkv, tables, attn, lse = ctx.saved_tensors
-        B, N, H, scale, w = ctx.cfg
+        B, N, H, scale, w = ctx.cfg[:5]
+        drop = ctx.cfg[5] if len(ctx.cfg) > 5 else NO_DROP
         D = x.shape[1]
         dt = x.dtype
-        dqkv, dtab = _attn_bwd(qkv, B, N, H, D // H, tables, scale, w, attn, dattn.contiguous(), lse)
+        dqkv, dtab = _attn_bwd(qkv, B, N, H, D // H, tables, scale, w, attn, dattn.contiguous(), lse, drop=drop)
         dbqkv = ops.colsum(dqkv)
         dwqkv = _dw(dqkv, x)
         dx = _dx(dqkv, (wq, wk, wv))
@@ -653,25 +683,56 @@ class MlpFn(torch.autograd.Function):
     """act(x W1^T + b1) W2^T + b2 with the activation fused into the GEMM epilogues."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act, add_input=False):
+    def forward(ctx, x, w1, b1, w2, b2, act, add_input=False, drop1=NO_DROP, drop2=NO_DROP):
         dt = x.dtype
-        y, hmid, pre = _mlp_fwd(x, shadow(w1, dt), _f32(b1), shadow(w2, dt), _f32(b2), act, x if add_input else None)
-        ctx.save_for_backward(x, w1, w2, hmid, pre)
         ctx.act = act
         ctx.add_input = add_input
+        ctx.drops = (drop1, drop2)
+        if drop1[0] == 0.0 and drop2[0] == 0.0:
+            y, hmid, pre = _mlp_fwd(x, shadow(w1, dt), _f32(b1), shadow(w2, dt), _f32(b2), act, x if add_input else None)
+            ctx.save_for_backward(x, w1, w2, hmid, pre)
+            return y
+        # drop1 after the activation (timm Mlp's first drop, model.py:202 self.dropout), drop2 on the output (timm Mlp's
+        # second drop / dropout2 / dropout_out), the residual added after it
+        fwd_code, _ = _act_codes(act)
+        pre = torch.empty(x.shape[0], w1.shape[0], device=x.device, dtype=dt) if act == 'gelu' else None
+        hmid = ops.gemm(x, shadow(w1, dt), bias=_f32(b1), act=fwd_code, aux_out=pre)
+        hd = ops.dropout(hmid, drop1) if drop1[0] > 0.0 else hmid
+        res = x if add_input else None
+        if drop2[0] > 0.0:
+            y = ops.dropout(ops.gemm(hd, shadow(w2, dt), bias=_f32(b2)), drop2, res=res)
+        else:
+            y = ops.gemm(hd, shadow(w2, dt), bias=_f32(b2), residual=res)
+        ctx.save_for_backward(x, w1, w2, hmid, pre)      # the dropped activation is regenerated in backward
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w1, w2, hmid, pre = ctx.saved_tensors
         dy = dy.contiguous()
-        dx, dw1, db1, dw2, db2 = _mlp_bwd(dy, x, w1, w2, ctx.act, hmid, pre, dy if ctx.add_input else None)
-        return dx, dw1, db1, dw2, db2, None, None
+        drop1, drop2 = ctx.drops
+        if drop1[0] == 0.0 and drop2[0] == 0.0:
+            dx, dw1, db1, dw2, db2 = _mlp_bwd(dy, x, w1, w2, ctx.act, hmid, pre, dy if ctx.add_input else None)
+            return dx, dw1, db1, dw2, db2, None, None, None, None
+        _, bwd_code = _act_codes(ctx.act)
+        dyl = ops.dropout(dy, drop2) if drop2[0] > 0.0 else dy
+        hd = ops.dropout(hmid, drop1) if drop1[0] > 0.0 else hmid
+        db2 = ops.colsum(dyl)
+        dw2 = _dw(dyl, hd)
+        # the activation's derivative and the first dropout are both element-wise factors: they commute
+        dpre = _dx(dyl, w2, act=bwd_code, aux_in=pre if ctx.act == 'gelu' else hmid)
+        if drop1[0] > 0.0:
+            dpre = ops.dropout(dpre, drop1)
+        db1 = ops.colsum(dpre)
+        dw1 = _dw(dpre, x)
+        dx = _dx(dpre, w1, residual=dy if ctx.add_input else None)
+        return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
-def mlp(x2d, w1, b1, w2, b2, act='gelu', add_input=False):
-    """add_input: y = mlp(x) + x (the post-LN layers' residual, fused into the fc2 epilogue)."""
-    return MlpFn.apply(x2d, w1, b1, w2, b2, act, add_input)
+def mlp(x2d, w1, b1, w2, b2, act='gelu', add_input=False, p_act=0.0, p_out=0.0):
+    """add_input: y = mlp(x) + x (the post-LN layers' residual, fused into the fc2 epilogue).  p_act / p_out: dropout
+    after the activation / on the output (before the residual); each draws a stream when > 0."""
+    return MlpFn.apply(x2d, w1, b1, w2, b2, act, add_input, VD.next_stream(p_act), VD.next_stream(p_out))
 
 
 # --------------------------------------------------------------------------- FAVOR+ (Performer)

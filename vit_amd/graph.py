@@ -26,6 +26,10 @@ class GraphedTrainStep:
     def __init__(self, net, optimizer, img, target, epoch=None, smoothing=0.1, warmup=3):
         if not isinstance(optimizer, AdamW) or not optimizer.capturable:
             raise ValueError('GraphedTrainStep needs vit_amd.optim.AdamW(capturable=True)')
+        from . import dropout as VD
+        if VD.active(net):
+            raise ValueError('GraphedTrainStep: dropout is active (p > 0 in training mode); a captured graph bakes the '
+                             'dropout streams into its kernel arguments and every replay would repeat the same masks')
         self.net, self.optimizer, self.epoch, self.smoothing = net, optimizer, epoch, smoothing
         self.img = img.clone()
         self.target = target.clone()

@@ -100,12 +100,13 @@ class TransformerEncoderLayer(ComputeDtypeMixin, nn.Module):
 
     def forward2d(self, x2, B, N, epoch=None):
         a = self.self_attn
-        _check_p0(self, a.dropout, self.dropout.p, self.dropout1.p, self.dropout2.p)
         if hasattr(a, 'forward2d'):      # a FAVOR+ attention swapped in (model.Performer)
             return self._forward2d_generic(x2, B, N)
         H = a.num_heads
         D = x2.shape[1]
         scale = float(D // H) ** -0.5
+        if self.training and (a.dropout > 0 or self.dropout.p > 0 or self.dropout1.p > 0 or self.dropout2.p > 0):
+            return self._forward2d_dropout(x2, B, N, H, scale)
         if self.norm1.eps != self.norm2.eps:
             raise NotImplementedError('TransformerEncoderLayer: norm1 / norm2 must share eps')
         if self.normalize_before:
@@ -121,19 +122,44 @@ class TransformerEncoderLayer(ComputeDtypeMixin, nn.Module):
                                    self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                                    self.norm2.weight, self.norm2.bias, cfg)
 
+    def _forward2d_dropout(self, x2, B, N, H, scale):
+        """Training with dropout (the reference default 0.1, model.py:160-203): the block as separate autograd nodes.
+        Sites in the reference's order: attention probabilities (nn.MultiheadAttention's dropout), dropout1 on the
+        projected attention output, self.dropout after the activation, dropout2 on the MLP output."""
+        a = self.self_attn
+        ln = VF.layer_norm
+        D = x2.shape[1]
+
+        def attend(h, res):
+            qkv = VF.linear(h, a.in_proj_weight, a.in_proj_bias)
+            ctx = VF.attention(qkv, None, B, N, H, D // H, scale, None, p_drop=a.dropout)
+            y = VF.linear(ctx, a.out_proj.weight, a.out_proj.bias)
+            return VF.dropout(y, self.dropout1.p, res=res)
+
+        def ffn(h, res):
+            y = VF.mlp(h, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                       self.activation, p_act=self.dropout.p, p_out=self.dropout2.p)
+            return y + res
+
+        if self.normalize_before:
+            x2 = attend(ln(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps), x2)
+            return ffn(ln(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps), x2)
+        x2 = ln(attend(x2, x2), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        return ln(ffn(x2, x2), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+
     def _forward2d_generic(self, x2, B, N):
         """Block around an attention module that brings its own forward2d (FAVOR+)."""
         a = self.self_attn
         ln = VF.layer_norm
+        p1, pa, p2 = (self.dropout1.p, self.dropout.p, self.dropout2.p) if self.training else (0., 0., 0.)
+        mlp = lambda h: VF.mlp(h, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,   # noqa: E731
+                               self.activation, p_act=pa, p_out=p2)
         if self.normalize_before:
-            x2 = x2 + a.forward2d(ln(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, N)
+            x2 = VF.dropout(a.forward2d(ln(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, N), p1, res=x2)
             h = ln(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            return x2 + VF.mlp(h, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                               self.activation)
-        x2 = ln(x2 + a.forward2d(x2, B, N), self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        m = VF.mlp(x2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                   self.activation)
-        return ln(x2 + m, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return x2 + mlp(h)
+        x2 = ln(VF.dropout(a.forward2d(x2, B, N), p1, res=x2), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        return ln(x2 + mlp(x2), self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
     def forward(self, src, pos=None):
         """[N, B, D] -> [N, B, D] (the reference layout)."""
@@ -212,13 +238,16 @@ class MultiheadAttentionPerformer(ComputeDtypeMixin, nn.MultiheadAttention):
 
     def forward2d(self, x2, B, N):
         """[B*N, E] batch-major rows in compute dtype -> [B*N, E]."""
-        _check_p0(self, self.dropout)
         if not self._qkv_same_embed_dim:
             raise NotImplementedError('separate q/k/v embedding dims are not used by the reference models')
         if self.w is None:
             self.w = gaussian_orthogonal_random_matrix(self.m, self.head_dim, device=x2.device)
         qkv = VF.linear(x2, self.in_proj_weight, self.in_proj_bias)
         y = VF.favor_attention(qkv, self.w.to(x2.device), B, N, self.num_heads, self.head_dim, self.kernel, self.ratio())
+        if self.training and self.dropout > 0:
+            # the reference drops the NUMERATOR before dividing by the normaliser (model.py:305); the normaliser is one
+            # scalar per (token, head) and is not dropped, so that equals dropping the quotient element-wise
+            y = VF.dropout(y, self.dropout)
         return VF.linear(y, self.out_proj.weight, self.out_proj.bias)
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None):

@@ -268,21 +268,25 @@ def token_grads(dx, dpos, dcls):
           'vitk_token_grads')
 
 
-def attn_fwd(qkv_q, qkv_k, qkv_v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w):
+NO_DROP = (0.0, 0, 0)     # (p, seed, offset) of a dropout site that is off
+
+
+def attn_fwd(qkv_q, qkv_k, qkv_v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, drop=NO_DROP):
     """q/k/v: views into [B*N, ld]-strided buffers (element (b,n,h,d) at (b*N+n)*ld + h*dh + d).
-    pk/pq: band tables [2N-1, ld_p] (row r <-> i-j = r-(N-1)) or None.  Returns (out [B*N, H*dh], lse [B,H,N])."""
+    pk/pq: band tables [2N-1, ld_p] (row r <-> i-j = r-(N-1)) or None.  drop = (p, seed, offset): dropout on the
+    probabilities (vit_amd.dropout).  Returns (out [B*N, H*dh], lse [B,H,N])."""
     _req_cuda(qkv_q, qkv_k, qkv_v, pk, pq)
     out = torch.empty(B * N, H * dh, device=qkv_q.device, dtype=qkv_q.dtype)
     lse = torch.empty(B, H, N, device=qkv_q.device, dtype=torch.float32)
     st = lib().vitk_attn_fwd(_dt(qkv_q), B, H, N, dh, qkv_q.data_ptr(), qkv_k.data_ptr(), qkv_v.data_ptr(), ld,
                              _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
-                             out.data_ptr(), H * dh, lse.data_ptr(), _stream())
+                             out.data_ptr(), H * dh, lse.data_ptr(), float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     check(st, 'vitk_attn_fwd')
     return out, lse
 
 
 def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, lse, dq, dk, dv, ld_d, dpk, dpq,
-             workspace=None, ld_dp=None):
+             workspace=None, ld_dp=None, drop=NO_DROP):
     """dq/dk/dv: views into a [B*N, ld_d] buffer (same addressing as q/k/v).  dpk/dpq: fp32
     [2N-1, H*dh] (row stride ld_dp, default H*dh), ACCUMULATED into (caller zeroes).  ``workspace``: optional uint8 scratch of at
     least attn_bwd_workspace_bytes(...) (allocated when not given)."""
@@ -298,8 +302,38 @@ def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, l
                              _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
                              out.data_ptr(), dout.data_ptr(), H * dh, lse.data_ptr(),
                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d,
-                             _ptr(dpk), _ptr(dpq), H * dh if ld_dp is None else ld_dp, workspace.data_ptr(), _stream())
+                             _ptr(dpk), _ptr(dpq), H * dh if ld_dp is None else ld_dp, workspace.data_ptr(),
+                             float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     check(st, 'vitk_attn_bwd')
+
+
+def dropout(x, drop, res=None, out=None):
+    """y = x * keep / (1 - p) [+ res] on 2-D rows; drop = (p, seed, offset).  Element (r, c) is element r * cols + c of
+    the stream, so the backward is the same call on dy."""
+    _req_cuda(x, res, out)
+    px, rows, cols, ldx = _rows2d(x, 'dropout x')
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=x.dtype)
+    py, ry, cy, ldy = _rows2d(out, 'dropout out')
+    if (ry, cy) != (rows, cols) or out.dtype != x.dtype:
+        raise ValueError('dropout: out must match x')
+    pr = ldr = 0
+    if res is not None:
+        pr, rr, cr, ldr = _rows2d(res, 'dropout res')
+        if (rr, cr) != (rows, cols) or res.dtype != x.dtype:
+            raise ValueError('dropout: res must match x')
+    st = lib().vitk_dropout(_dt(x), rows, cols, px, ldx, pr, ldr, py, ldy, float(drop[0]), int(drop[1]), int(drop[2]),
+                            _stream())
+    check(st, 'vitk_dropout')
+    return out
+
+
+def dropout_mask(n, drop, device='cuda'):
+    """keep[i] (uint8) of the first n elements of the stream drop = (p, seed, offset): what the kernels apply (test hook)."""
+    out = torch.empty(n, device=device, dtype=torch.uint8)
+    check(lib().vitk_dropout_mask(n, float(drop[0]), int(drop[1]), int(drop[2]), out.data_ptr(), _stream()),
+          'vitk_dropout_mask')
+    return out
 
 
 FAVOR_SOFTMAX, FAVOR_RELU = 0, 1

@@ -40,10 +40,12 @@ def lai_stage_width(epoch, mask_epochs):
 
 
 def _check_p0(module, *ps):
+    """For the one stochastic regulariser that is not built: DropPath (stochastic depth; 0 at every call site of the
+    reference's train.py).  nn.Dropout sites are implemented (vit_amd.dropout)."""
     if module.training and any(p > 0 for p in ps):
         raise NotImplementedError(
-            'vit_amd kernels implement dropout p = 0 only (parity with the reference is defined at p = 0); '
-            'construct the module with drop rates 0 or call .eval()')
+            'DropPath (stochastic depth) is not implemented: the reference never sets drop_path_rate (train.py:167-194); '
+            'construct the module with drop_path_rate = 0 or call .eval()')
 
 
 class Mlp(nn.Module):
@@ -89,15 +91,24 @@ class AttentionLAI(ComputeDtypeMixin, nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.mask_epochs = mask_epochs
 
-    def forward(self, x, epoch):
-        _check_p0(self, self.attn_drop.p, self.proj_drop.p)
-        B, N, C = x.shape
-        dt = self.compute_dtype
-        x2 = x.reshape(B * N, C).to(dt)
+    def forward2d(self, x2, B, N, epoch, res=None):
+        """[B*N, C] in compute dtype -> proj_drop(proj(softmax-attention)) [+ res]; attn_drop acts on the probabilities
+        inside the attention kernel (reference :74), proj_drop on the projected output (:78)."""
+        C = x2.shape[1]
+        p_attn = self.attn_drop.p if self.training else 0.
+        p_proj = self.proj_drop.p if self.training else 0.
         qkv = VF.linear(x2, self.qkv.weight, self.qkv.bias)
         ctx = VF.attention(qkv, None, B, N, self.num_heads, C // self.num_heads, float(self.scale),
-                           lai_stage_width(epoch, self.mask_epochs))
-        y = VF.linear(ctx, self.proj.weight, self.proj.bias)
+                           lai_stage_width(epoch, self.mask_epochs), p_drop=p_attn)
+        if p_proj > 0:
+            return VF.dropout(VF.linear(ctx, self.proj.weight, self.proj.bias), p_proj, res=res)
+        if res is not None:
+            return VF.linear_res(ctx, self.proj.weight, self.proj.bias, res)
+        return VF.linear(ctx, self.proj.weight, self.proj.bias)
+
+    def forward(self, x, epoch):
+        B, N, C = x.shape
+        y = self.forward2d(x.reshape(B * N, C).to(self.compute_dtype), B, N, epoch)
         return y.view(B, N, C).to(x.dtype)
 
 
@@ -118,12 +129,21 @@ class BlockLAI(ComputeDtypeMixin, nn.Module):
     def forward2d(self, x2, B, N, epoch):
         """x2: [B*N, C] in compute dtype -> same.  The whole block is one autograd node."""
         a = self.attn
-        _check_p0(self, a.attn_drop.p, a.proj_drop.p, self.mlp.drop.p, self.drop_path_rate)
+        _check_p0(self, self.drop_path_rate)
+        p_mlp = self.mlp.drop.p if self.training else 0.
         if not isinstance(a, AttentionLAI):      # an attention swapped in (FAVOR+, train.py:147-165)
             x2 = x2 + a.forward2d(VF.layer_norm(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, N)
             h = VF.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
             return x2 + VF.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
-                               'gelu')
+                               'gelu', p_act=p_mlp, p_out=p_mlp)
+        if self.training and (a.attn_drop.p > 0 or a.proj_drop.p > 0 or p_mlp > 0):
+            # training with dropout (train.py:179,191 pass attn_drop_rate = --dropout): the block as separate autograd
+            # nodes, dropout sites in the reference's order (probabilities, proj output, Mlp activation, Mlp output)
+            x2 = a.forward2d(VF.layer_norm(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, N, epoch, res=x2)
+            h = VF.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            y = VF.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, 'gelu',
+                       p_act=p_mlp, p_out=p_mlp)
+            return x2 + y
         if self.norm1.eps != self.norm2.eps:
             raise NotImplementedError('BlockLAI: norm1 / norm2 must share eps')
         cfg = (B, N, a.num_heads, self.norm1.eps, float(a.scale), lai_stage_width(epoch, a.mask_epochs), 'gelu')
@@ -182,7 +202,6 @@ class VisionTransformerLAI(ComputeDtypeMixin, nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward_features(self, x, epoch):
-        _check_p0(self, self.pos_drop.p)
         norm = getattr(self, 'input_norm', None)
         self.patch_embed.check(x.permute(0, 3, 1, 2) if (x.dtype == torch.uint8 and norm and norm[2] == 'nhwc') else x)
         B = x.shape[0]
@@ -191,6 +210,8 @@ class VisionTransformerLAI(ComputeDtypeMixin, nn.Module):
         D = self.embed_dim
         tok = VF.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token,
                              self.pos_embed, dt, norm=norm)
+        if self.training and self.pos_drop.p > 0:      # x = self.pos_drop(x) (reference :139)
+            tok = VF.dropout(tok, self.pos_drop.p)
         for blk in self.blocks:
             tok = blk.forward2d(tok, B, N, epoch)
         cls = tok.view(B, N, D)[:, 0]           # LayerNorm is row-wise: normalise the class rows only

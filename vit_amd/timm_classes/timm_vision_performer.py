@@ -82,14 +82,18 @@ class PerformerAttention(ComputeDtypeMixin, Attention):
 
     def forward2d(self, x2, B, N):
         """[B*N, C] in compute dtype -> [B*N, C]."""
-        _check_p0(self, self.attn_drop.p, self.proj_drop.p)
         if self.w is None:
             self.w = gaussian_orthogonal_random_matrix(self.m, self.head_dim, device=x2.device)
         C = x2.shape[1]
         qkv = VF.linear(x2, self.qkv.weight, self.qkv.bias)
         y = VF.favor_attention(qkv, self.w.to(x2.device), B, N, self.num_heads, C // self.num_heads, self.kernel,
                                self.ratio())
-        return VF.linear(y, self.proj.weight, self.proj.bias)
+        if self.training and self.attn_drop.p > 0:     # attn_drop acts on the attention OUTPUT here (reference :61)
+            y = VF.dropout(y, self.attn_drop.p)
+        y = VF.linear(y, self.proj.weight, self.proj.bias)
+        if self.training and self.proj_drop.p > 0:     # reference :64
+            y = VF.dropout(y, self.proj_drop.p)
+        return y
 
     def forward(self, x):
         B, N, C = x.shape

@@ -31,13 +31,16 @@ def label_smoothing_ce(logits, target, smoothing=0.1):
 
 
 def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, num_classes=1000,
-                mask_epochs=None, dtype=torch.bfloat16, device='cuda', **over):
+                mask_epochs=None, dtype=torch.bfloat16, device='cuda', dropout=0.0, **over):
     """Model factory for the --attention variants on the hot path (train.py:97-253):
     'transformer' (regular, pre-LN, ReLU), 'transformer_timm_lai', 'disentangled_attention',
-    'disentangled_lai_attention', 'disentangled_performer', 'performer_timm', 'performer'.  Dropout is 0 (parity and benchmarks are defined at p = 0)."""
+    'disentangled_lai_attention', 'disentangled_performer', 'performer_timm', 'performer'.  ``dropout`` goes where the
+    reference's --dropout goes (train.py:79; dropout= of the model.py / disentangled stacks, attn_drop_rate of the timm
+    ones, attn_drop of PerformerAttention); the default here is 0 (benchmarks and reference parity are defined at
+    p = 0), the reference's is 0.1."""
     p = dict(PRESETS[preset], **{k: v for k, v in over.items() if k in ('depth', 'dim', 'mlp', 'heads')})
     if attention == 'transformer':
-        tr = M.Transformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+        tr = M.Transformer(d_model=p['dim'], dropout=dropout, nhead=p['heads'], dim_feedforward=p['mlp'],
                            num_encoder_layers=p['depth'], normalize_before=True)
         net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
                                   num_classes=num_classes, transformer=tr)
@@ -45,10 +48,10 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
         net = VisionTransformerLAI(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
                                    num_classes=num_classes, embed_dim=p['dim'], depth=p['depth'],
                                    num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'], qkv_bias=True,
-                                   mask_epochs=mask_epochs)
+                                   attn_drop_rate=dropout, mask_epochs=mask_epochs)
     elif attention in ('disentangled_attention', 'disentangled_lai_attention'):
         lai = attention == 'disentangled_lai_attention'
-        tr = DisentangledTransformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+        tr = DisentangledTransformer(d_model=p['dim'], dropout=dropout, nhead=p['heads'], dim_feedforward=p['mlp'],
                                      num_encoder_layers=p['depth'], normalize_before=True, pos_att_type='c2p|p2c',
                                      max_position_embeddings=p['dim'], relative_attention=True, lai=lai,
                                      mask_epochs=mask_epochs if lai else None)
@@ -56,7 +59,7 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
                                   num_classes=num_classes, transformer=tr)
     elif attention == 'disentangled_performer':
         # train.py:215-234: FAVOR+ with position features inside the DeBERTa-style post-LN layers
-        tr = DisentangledTransformer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+        tr = DisentangledTransformer(d_model=p['dim'], dropout=dropout, nhead=p['heads'], dim_feedforward=p['mlp'],
                                      num_encoder_layers=p['depth'], normalize_before=True, pos_att_type='c2p|p2c',
                                      max_position_embeddings=p['dim'], relative_attention=True, performers=True,
                                      norf=over.get('num_orf', 16), kernel=over.get('kernel', 'softmax'))
@@ -67,12 +70,12 @@ def build_model(attention, preset='B', img_size=224, patch_size=16, in_chans=3, 
         net = VisionTransformerLAI(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
                                    num_classes=num_classes, embed_dim=p['dim'], depth=p['depth'],
                                    num_heads=p['heads'], mlp_ratio=p['mlp'] / p['dim'], qkv_bias=True,
-                                   mask_epochs=None)
+                                   attn_drop_rate=dropout, mask_epochs=None)
         for blk in net.blocks:
-            blk.attn = PerformerAttention(blk.attn, p['dim'], num_heads=p['heads'], qkv_bias=True,
+            blk.attn = PerformerAttention(blk.attn, p['dim'], num_heads=p['heads'], qkv_bias=True, attn_drop=dropout,
                                           n_orf=over.get('num_orf', 64), kernel=over.get('kernel', 'softmax'))
     elif attention == 'performer':
-        tr = M.Performer(d_model=p['dim'], dropout=0.0, nhead=p['heads'], dim_feedforward=p['mlp'],
+        tr = M.Performer(d_model=p['dim'], dropout=dropout, nhead=p['heads'], dim_feedforward=p['mlp'],
                          num_encoder_layers=p['depth'], normalize_before=True,
                          num_orf=over.get('num_orf', 64), kernel=over.get('kernel', 'softmax'))
         net = M.VisionTransformer(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
