@@ -2,6 +2,7 @@
 // worth of 16-byte stores in different shapes.  hipcc --offload-arch=gfx950 -O3 store_rate.hip -o store_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -36,9 +37,9 @@ __global__ void k(char* out, long ld, int waves_active, long* cyc, int wait) {
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const long ld = 8192;   // bytes per row (N = 4096 bf16)
-    const int blocks = 256;
+    const int blocks = argc > 1 ? atoi(argv[1]) : 256;   // 8: one workgroup per XCD; 64: eight per XCD
     char* out; long* cyc;
     hipMalloc(&out, (size_t)blocks * 256 * ld);
     hipMalloc(&cyc, blocks * 8 * sizeof(long));
@@ -56,7 +57,7 @@ int main() {
                 hipMemcpy(h.data(), cyc, blocks * 8 * sizeof(long), hipMemcpyDeviceToHost);
                 double s = 0, mx = 0; int n = 0;
                 for (int b = 0; b < blocks; ++b) for (int w = 0; w < wa; ++w) { s += h[b * 8 + w]; if (h[b*8+w] > mx) mx = h[b*8+w]; ++n; }
-                printf("wait=%d waves=%d mode=%d: mean %.0f cycles, max %.0f per wave for 16 stores (%d KB per CU)\n", wait, wa, mode, s / n, mx, wa * 16);
+                printf("blocks=%d wait=%d waves=%d mode=%d: mean %.0f cycles, max %.0f per wave for 16 stores (%d KB per CU)\n", blocks, wait, wa, mode, s / n, mx, wa * 16);
             }
     return 0;
 }

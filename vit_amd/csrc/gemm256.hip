@@ -462,6 +462,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     const int nitems = p.tiles_m * p.tiles_n * p.splitk;
     int item = blockIdx.x;
     if (item >= nitems) return;
+    // Stagger: when every CU of an XCD reaches its epilogue at the same time, the 32 of them share that XCD's L2
+    // write path (128 KiB per CU take 4.6 k cycles, against 1.9 k for a CU storing alone: tools/micro/store_rate.hip)
+    // and each CU's next loads queue behind its own stores.  Workgroups that walk one item FEWER than the busiest
+    // ones have a whole tile time of slack: the later quarters of each XCD's workgroups (blockIdx >> 3 >= 8), as far as
+    // it has that slack, starts late -- in `groups` phases spread over 75 % of a tile time -- so that only a fraction of
+    // an XCD stores at any time.  Same-box A/B on the layer's NT GEMMs: -2.9 % (dX fc2 -6 %, dX qkv -4 %, fc2 -3 %).
+    if (p.stagger > 0) {
+        const int rem = nitems % (int)gridDim.x;           // workgroups below `rem` walk one item more
+        const int groups = p.stagger >> 24, ticks = p.stagger & 0xffffff;      // phase g of `groups` starts g * ticks late
+        const int ph = (int)(blockIdx.x >> 3) * groups / 32;
+        if (nitems > (int)gridDim.x && rem != 0 && (int)blockIdx.x >= rem && ph > 0) {
+            const long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (long)ticks * ph) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(p.A);
     const __bf16* __restrict__ B = reinterpret_cast<const __bf16*>(p.B);
@@ -706,7 +721,21 @@ bool gemm256_eligible(const GemmParams& p, int transA, int transB) {
     return true;
 }
 
-void gemm256_launch(const GemmParams& p, int c_dtype, int transA, int transB, hipStream_t stream) {
+void gemm256_launch(const GemmParams& p0, int c_dtype, int transA, int transB, hipStream_t stream) {
+    GemmParams p = p0;
+    // half a tile time in shader clock ticks (3.6 k per 64-deep K tile + epilogue); only plain-store epilogues
+    static int pct = -1, groups = 4;       // VITK_GEMM_STAGGER = total spread in % of a tile time (0: off), _GROUPS = phases
+    if (pct < 0) {
+        const char* e = getenv("VITK_GEMM_STAGGER");
+        pct = e ? atoi(e) : 75;
+        const char* g = getenv("VITK_GEMM_STAGGER_GROUPS");
+        groups = g ? atoi(g) : 4;
+        if (groups < 2 || groups > 32) groups = 4;
+    }
+    const long tile_ticks = (long)p.K / 64 * 3600 + 10000;
+    long ticks = tile_ticks * pct / 100 / (groups - 1);    // spacing between consecutive phases: the last one starts pct % of a tile late
+    if (ticks > 0xffffff) ticks = 0xffffff;
+    p.stagger = (pct > 0 && p.splitk == 1) ? (int)((groups << 24) | ticks) : 0;
     if (c_dtype == VITK_BF16) launch256<__bf16>(p, transA, transB, stream);
     else launch256<float>(p, transA, transB, stream);
 }

@@ -31,6 +31,7 @@ struct GemmParams {
     float alpha;
     int tiles_m, tiles_n;
     int debug;
+    int stagger;             // 256-tile kernel: start delay (shader clock ticks) of the workgroups that can afford one, 0 = none
 };
 
 
