@@ -153,7 +153,10 @@ int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void* q, const v
                   const void* out, const void* dout, long ldo, const float* lse,
                   void* dq, void* dk, void* dv, long ld_d, float* dpk, float* dpq, long ld_dp,
                   void* workspace, float drop_p, unsigned long long drop_seed, unsigned long long drop_offset,
-                  void* stream);
+                  float* dbias, void* stream);
+/* dbias (may be NULL): fp32 [3 * H * dh] (q | k | v), += the column sums of dq / dk / dv over all B*N tokens: the bias
+ * gradient of the fused q/k/v projection (query_proj / key_proj / value_proj.bias, disentangled_transformer.py:854-856;
+ * qkv.bias, timm_locality_aware_transformer.py:48) straight from the kernel that holds dQ / dK / dV in registers. */
 
 /* FAVOR+ (Performer) attention: feature maps + linear-attention contraction + normaliser, between
  * the qkv projection and the output projection.  Replaces PerformerAttention.forward :36-59 with

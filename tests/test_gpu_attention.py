@@ -74,8 +74,9 @@ def test_attn_bwd(dtype, bias, w, B, N, H, dh):
     if bias:
         dpk = torch.zeros(2 * N - 1, D, device='cuda')
         dpq = torch.zeros(2 * N - 1, D, device='cuda')
+    dbias = torch.ones(3 * D, device='cuda')                  # accumulated into: starts at 1
     ops.attn_bwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, w, out, dout, lse,
-                 dq, dk, dv, dqkv.stride(0), dpk, dpq)
+                 dq, dk, dv, dqkv.stride(0), dpk, dpq, dbias=dbias)
     # fp64 autograd of the closed form on the same (rounded) inputs
     f = lambda t: t.double().reshape(B, N, H, dh).clone().requires_grad_(True)
     qr, kr, vr = f(q), f(k), f(v)
@@ -92,3 +93,6 @@ def test_attn_bwd(dtype, bias, w, B, N, H, dh):
     if bias:
         assert relerr(dpk.view(-1, H, dh), pkr.grad) < tol
         assert relerr(dpq.view(-1, H, dh), pqr.grad) < tol
+    # the fused q|k|v bias gradient: column sums of dq | dk | dv over every token
+    db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
+    assert relerr(dbias, db_ref) < tol

@@ -264,4 +264,4 @@ def test_ext_workspace_not_shared_between_layouts():
     after = grads(xb, yb)
     for n in alone:
         scale = alone[n].abs().max().clamp_min(1e-12)
-        assert ((alone[n] - after[n]).abs().max() / scale).item() < 1e-3, n    # split-K atomics reorder fp32 sums; stale rows would be O(1)
+        assert ((alone[n] - after[n]).abs().max() / scale).item() < 1e-2, n    # atomics reorder fp32 sums and a bf16 rounding of them can flip (~2e-3 seen); stale rows would be O(1)

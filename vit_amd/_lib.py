@@ -48,7 +48,7 @@ _SIGNATURES = {
     'vitk_attn_bwd': ([c_int, c_int, c_int, c_int, c_int,
                        c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long,
                        c_float, c_int, c_vp, c_vp, c_long, c_vp,
-                       c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_float, c_u64, c_u64, c_vp], c_int),
+                       c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_float, c_u64, c_u64, c_vp, c_vp], c_int),
     'vitk_dropout': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_long, c_vp, c_long, c_float, c_u64, c_u64, c_vp], c_int),
     'vitk_dropout_mask': ([c_long, c_float, c_u64, c_u64, c_vp, c_vp], c_int),
     'vitk_attn_bwd_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),

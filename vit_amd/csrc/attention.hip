@@ -229,6 +229,7 @@ struct BandParams {
     int w;
     __bf16* ds_ws;
     DropParams drop;
+    float* dbias;
 };
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
 void band_launch(const BandParams& p, bool backward, hipStream_t st);

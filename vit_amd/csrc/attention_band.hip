@@ -23,6 +23,7 @@
 // softmax state / gradient accumulators stay in registers across groups -- and the next group's
 // rows replace them (two workgroup barriers per group).  Every LAI stage of the reference
 // (w = 8..20) is a single group; the unmasked disentangled stage of 197 tokens is five.
+#include <type_traits>
 #include "attn_common.h"
 
 namespace vitk {
@@ -57,6 +58,8 @@ struct BandParams {
     int w;
     __bf16* ds_ws;          // backward with the bias: dS tiles for the table-gradient kernel (attention_bwd.hip)
     DropParams drop;        // dropout on the probabilities, element ((b*H + h)*N + i)*N + j of the stream (attention.hip)
+    float* dbias;           // backward, optional: [3 * H * dh] fp32 (q | k | v), += the column sums of dQ / dK / dV over all
+                            // tokens -- the bias gradient of the fused qkv projection, without a pass over dqkv
 };
 
 template <int DKB, bool BIAS> struct BandCfg {
@@ -72,7 +75,7 @@ template <int DKB, bool BIAS> struct BandCfg {
         cmax = cmax < BAND_GC ? cmax : BAND_GC;
         const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
         return rows * ASTR * 2 + (size_t)2 * (16 * NT + 16) * 4 +
-               (size_t)BAND_WAVES * ((BIAS ? 2 * SCR_FLOATS : 0) + BAND_DS_FLOATS) * 4;
+               (size_t)BAND_WAVES * ((BIAS ? 2 * SCR_FLOATS : 0) + BAND_DS_FLOATS) * 4 + 3 * 64 * 4;   // + column sums
     }
 };
 
@@ -246,6 +249,19 @@ __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const B
 }
 
 // ----------------------------------------------------------------------------------------- backward
+// Sum over the 16 lanes of a DPP row (the lanes that share lane >> 4), in every lane of the row: two quad
+// permutes and two row rotations, all on the VALU (a __shfl_xor would go through the LDS pipe).
+__device__ inline float row16_sum(float t) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    t += dpp(t, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    t += dpp(t, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    t += dpp(t, std::integral_constant<int, 0x124>{});   // row_ror:4
+    t += dpp(t, std::integral_constant<int, 0x128>{});   // row_ror:8
+    return t;
+}
+
 template <int DKB, bool BIAS>
 __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandParams p) {
     using T = __bf16;
@@ -274,6 +290,22 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     float* xs = scr + wave * WSCR;
     float* ys = xs + (BIAS ? SCR_FLOATS : 0);
     float* dsc = ys + (BIAS ? SCR_FLOATS : 0);   // padded dS copy (attn_common.h)
+    float* colacc = scr + BAND_WAVES * WSCR;      // [3][64]: column sums of dQ / dK / dV of this head (p.dbias)
+    const bool want_bias = p.dbias != nullptr;
+    if (want_bias && tid < 192) colacc[tid] = 0.f;
+    // sum over the wave's tiles and its 16 key / query lanes, then one LDS atomic per (group, d)
+    auto colsum_acc = [&](const f32x4 (&acc)[BAND_TPW][ND], float* dst) {
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < BAND_TPW; ++s2) t += acc[s2][dt][r];
+                t = row16_sum(t);
+                if (li == 0) atomicAdd(dst + 16 * dt + 4 * g + r, t);
+            }
+    };
 
     const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * dh;
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
@@ -413,6 +445,10 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                 }
             }
         }
+        if (want_bias) {     // tiles / keys past N hold zeros
+            colsum_acc(dkacc, colacc + 64);
+            colsum_acc(dvacc, colacc + 128);
+        }
 #pragma unroll
         for (int s = 0; s < BAND_TPW; ++s) {
             const int kj = 16 * (wave + BAND_WAVES * s) + li;
@@ -502,6 +538,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                 }
             }
         }
+        if (want_bias) colsum_acc(dqacc, colacc);
 #pragma unroll
         for (int s = 0; s < BAND_TPW; ++s) {
             const int qi = 16 * (wave + BAND_WAVES * s) + li;
@@ -516,6 +553,13 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                     }
                 }
             }
+        }
+    }
+    if (want_bias) {     // one contiguous 256-byte atomic per matrix and head
+        __syncthreads();
+        if (tid < 192) {
+            const int which = tid >> 6, d = tid & 63;
+            if (d < dh) atomicAdd(p.dbias + (long)which * p.H * dh + h * dh + d, colacc[tid]);
         }
     }
 }

@@ -911,12 +911,15 @@ struct BandParams {
     int w;
     __bf16* ds_ws;
     DropParams drop;
+    float* dbias;
 };
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
 void band_launch(const BandParams& p, bool backward, hipStream_t st);
 }  // namespace vitk
 
 using namespace vitk;
+
+extern "C" int vitk_colsum(int dtype, int M, int N, const void* X, long ldx, float* out, hipStream_t stream);
 
 static bool b16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -941,7 +944,7 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
                              long ld, const void* pk, const void* pq, long ld_p, float scale, int band_w,
                              const void* out, const void* dout, long ldo, const float* lse, void* dq, void* dk,
                              void* dv, long ld_d, float* dpk, float* dpq, long ld_dp, void* workspace,
-                             float drop_p, unsigned long long drop_seed, unsigned long long drop_offset,
+                             float drop_p, unsigned long long drop_seed, unsigned long long drop_offset, float* dbias,
                              hipStream_t stream) {
     VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "vitk_attn_bwd: bad dtype");
     VITK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "vitk_attn_bwd: dropout p must be in [0, 1)");
@@ -1000,6 +1003,7 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
         bp.B = B; bp.H = H; bp.N = N; bp.dh = dh;
         bp.scale = scale; bp.w = band_w;
         bp.drop = p.drop;
+        bp.dbias = dbias;
         // pass 1 leaves its dS tiles behind delta: for pass 2 and for the table-gradient kernel
         bp.ds_ws = reinterpret_cast<__bf16*>(p.delta + ((long)B * H * N + 63) / 64 * 64);
         p.ds_ws = bp.ds_ws;
@@ -1043,5 +1047,12 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
         bwd_dispatch<float, 1>(p, zgroups, stream);
     }
     VITK_CHECK_LAUNCH("vitk_attn_bwd");
+    if (dbias) {     // the generic kernels keep no per-head sums: three column-sum passes over dq / dk / dv
+        const void* parts[3] = {dq, dk, dv};
+        for (int i = 0; i < 3; ++i) {
+            const int st = vitk_colsum(dtype, (int)rows, (int)HD, parts[i], ld_d, dbias + (long)i * HD, stream);
+            if (st != VITK_OK) return st;
+        }
+    }
     return VITK_OK;
 }

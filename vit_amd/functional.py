@@ -286,7 +286,7 @@ def _attn_fwd(qkv, B, N, H, dh, tables, scale, w, drop=NO_DROP):
     return ops.attn_fwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w, drop=drop)
 
 
-def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None, dqkv=None, drop=NO_DROP):
+def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None, dqkv=None, drop=NO_DROP, dbias=None):
     """Returns dqkv [B*N, 3D] and (for tables) fp32 dtables [2N-1, 2D] (dPq | dPk); ``dtab``: a
     zeroed buffer to accumulate into."""
     D = H * dh
@@ -306,7 +306,7 @@ def _attn_bwd(qkv, B, N, H, dh, tables, scale, w, out, dout, lse, dtab=None, dqk
             dtab = torch.zeros(2 * N - 1, 2 * D, device=qkv.device, dtype=torch.float32)
         dpq, dpk = dtab[:, :D], dtab[:, D:]
     ops.attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, -1 if w is None else w, out, dout, lse,
-                 dq, dk, dv, 3 * D, dpk, dpq, ld_dp=2 * D, drop=drop)
+                 dq, dk, dv, 3 * D, dpk, dpq, ld_dp=2 * D, drop=drop, dbias=dbias)
     return dqkv, dtab
 
 
@@ -431,8 +431,8 @@ class PreLNBlockFn(torch.autograd.Function):
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy, dxsum=dbproj)
         dwproj = _dw(dx1, attn, out=s_wproj if s_wproj is not None else zp.take(D, D))
         dattn = _dx(dx1, wproj)
-        dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse)
-        dbqkv = ops.colsum(dqkv, out=zp.take(3 * D)) if ctx.has_qkv_bias else None
+        dbqkv = zp.take(3 * D) if ctx.has_qkv_bias else None        # summed by the attention backward itself
+        dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse, dbias=dbqkv)
         dwqkv = _dw(dqkv, h1, out=s_wqkv if s_wqkv is not None else zp.take(3 * D, D))
         # a fresh alias of a slab view: autograd adopts it as .grad without a copy
         dw1, dw2, dwproj, dwqkv = (t.detach() if t is s else t
@@ -564,10 +564,11 @@ class DisLayerFn(torch.autograd.Function):
             dtab = zp.take(R, 2 * D)
         else:
             dqkv_ext = torch.empty(ME, 3 * D, device=x_ext.device, dtype=dt)
-        _attn_bwd(qkv_ext[:M1], B, N, H, dh, tables, scale, w, attn, dattn, lse, dtab=dtab, dqkv=dqkv_ext[:M1])
+        dbqkv = zp.take(3 * D)             # token rows: summed by the attention backward; table rows: below
+        _attn_bwd(qkv_ext[:M1], B, N, H, dh, tables, scale, w, attn, dattn, lse, dtab=dtab, dqkv=dqkv_ext[:M1], dbias=dbqkv)
         if band is not None:
             dqkv_ext[M1:M1 + R, :2 * D].copy_(dtab)               # (dPq | dPk) in compute dtype
-        dbqkv = ops.colsum(dqkv_ext, out=zp.take(3 * D))
+            ops.colsum(dtab, out=dbqkv[:2 * D])                   # the table rows went through the same projections
         dwqkv = _dw(dqkv_ext, x_ext, out=zp.take(3 * D, D))
         dx_ext = _dx(dqkv_ext, (wq, wk, wv), residual=ds1_ext)
         dx = dx_ext[:M1]

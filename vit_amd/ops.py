@@ -286,11 +286,14 @@ def attn_fwd(qkv_q, qkv_k, qkv_v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, 
 
 
 def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, lse, dq, dk, dv, ld_d, dpk, dpq,
-             workspace=None, ld_dp=None, drop=NO_DROP):
+             workspace=None, ld_dp=None, drop=NO_DROP, dbias=None):
     """dq/dk/dv: views into a [B*N, ld_d] buffer (same addressing as q/k/v).  dpk/dpq: fp32
     [2N-1, H*dh] (row stride ld_dp, default H*dh), ACCUMULATED into (caller zeroes).  ``workspace``: optional uint8 scratch of at
-    least attn_bwd_workspace_bytes(...) (allocated when not given)."""
-    _req_cuda(q, k, v, pk, pq, out, dout, lse, dq, dk, dv, dpk, dpq, workspace)
+    least attn_bwd_workspace_bytes(...) (allocated when not given).  ``dbias``: optional fp32 [3*H*dh], += column sums
+    of dq | dk | dv (the q/k/v bias gradient)."""
+    _req_cuda(q, k, v, pk, pq, out, dout, lse, dq, dk, dv, dpk, dpq, workspace, dbias)
+    if dbias is not None and (dbias.dtype != torch.float32 or dbias.numel() != 3 * H * dh or not dbias.is_contiguous()):
+        raise ValueError('attn_bwd: dbias must be contiguous fp32 [3*H*dh]')
     need = lib().vitk_attn_bwd_workspace_bytes(_dt(q), B, H, N, dh)
     if workspace is None:
         workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
@@ -303,7 +306,7 @@ def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, l
                              out.data_ptr(), dout.data_ptr(), H * dh, lse.data_ptr(),
                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d,
                              _ptr(dpk), _ptr(dpq), H * dh if ld_dp is None else ld_dp, workspace.data_ptr(),
-                             float(drop[0]), int(drop[1]), int(drop[2]), _stream())
+                             float(drop[0]), int(drop[1]), int(drop[2]), _ptr(dbias), _stream())
     check(st, 'vitk_attn_bwd')
 
 
