@@ -12,7 +12,11 @@ bf16 compute / fp32 master weights, LAI stage w = 20).  Rank 0 prints ONE JSON l
 
 Extra objects on the line:
   roofline     : the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs per launch / HIP-event
-                 time per launch, summed over every GEMM launch of the timed steps, vs 2.5 PF.
+                 time per launch, summed over every GEMM launch of the timed steps, vs 2.5 PF.  On the
+                 FAVOR+ workloads: the FAVOR+ kernels, algorithmic bytes vs 8 TB/s (bound "hbm").
+                 traffic = PMC bytes per launch from profiles/ (null when that file was measured on
+                 other kernel sources).
+  timed_kernels: the same line for every timed launch group (GEMM layouts, attention, FAVOR+).
   cpu_baseline : the CPU oracle (oracle/ref_cpu.py, the reference's algorithm in plain fp32
                  PyTorch) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -29,6 +33,7 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0         # HBM3E (same guide)
 
 WORKLOADS = {
     # name: (attention variant, preset, img, patch, classes, default per-GPU batch)
@@ -39,6 +44,8 @@ WORKLOADS = {
     'regular_cifar': ('transformer', 'cifar', 32, 4, 10, 128),
     'performer_s16_384': ('performer_timm', 'S', 384, 16, 1000, 64),      # config 5, FAVOR+ m = 64
     'disperf_s16': ('disentangled_performer', 'S', 224, 16, 1000, 128),   # SURVEY 8(f)-1, m = 16 (train.py:75)
+    # config 5's other leg: the same timm ViT-S/16-384 with its softmax attention left in place (577 tokens, no mask)
+    'softmax_s16_384': ('transformer_timm_lai', 'S', 384, 16, 1000, 64),
 }
 MASK_EPOCHS = [10, 20, 30, 40]
 STAGE_EPOCH = {8: 0, 12: 10, 18: 20, 20: 30, -1: 40}
@@ -166,6 +173,8 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     variant, preset, img, patch, classes, dbatch = WORKLOADS[args.workload]
+    if args.workload == 'softmax_s16_384':
+        args.band = -1
     B = args.batch or dbatch
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     p = PRESETS[preset]
@@ -224,30 +233,59 @@ def main():
     model_tflops_gpu = fl_img * B * args.steps / elapsed / 1e12
 
     roofline = None
+    kernels = None
     if timer:
         agg = {}
-        for name, fl, e0, e1 in timer:
-            a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += fl
+        for name, work, e0, e1, unit in timer:
+            a = agg.setdefault(name, [0.0, 0.0, 0, unit])
+            a[0] += work
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
-        dom = max(agg, key=lambda k: agg[k][1])
-        fl, sec, cnt = agg[dom]
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-        # HBM-side bytes per launch of that kernel: measured with rocprofv3 --pmc in runs of their own
-        # (FETCH_SIZE and WRITE_SIZE cannot share a pass, and PMC runs cannot be nested in this one);
-        # the committed summary of those passes over this same command is read here.
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic.json')
-        if args.workload == 'dislai_b16' and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': fl / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': fl / sec / 1e12 / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/)',
-                    'launches': cnt,
-                    'avg_launch_us': 1e6 * sec / cnt, 'avg_gflop_per_launch': fl / cnt / 1e9,
-                    'share_of_step_time': sec / elapsed,
-                    'all_gemm_tflops': sum(v[0] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e12,
-                    'all_gemm_share_of_step_time': sum(v[1] for v in agg.values()) / elapsed}
+
+        def line(name):
+            work, sec, cnt, unit = agg[name]
+            if unit == 'flop':
+                return {'bound': 'mfma', 'kernel': name, 'achieved': work / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': work / sec / 1e12 / peak, 'launches': cnt, 'avg_launch_us': 1e6 * sec / cnt,
+                        'avg_gflop_per_launch': work / cnt / 1e9, 'share_of_step_time': sec / elapsed}
+            return {'bound': 'hbm', 'kernel': name, 'achieved': work / sec / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': work / sec / 1e9 / PEAK_HBM_GBS, 'launches': cnt, 'avg_launch_us': 1e6 * sec / cnt,
+                    'avg_mb_per_launch': work / cnt / 1e6, 'share_of_step_time': sec / elapsed}
+
+        gemms = [k for k in agg if agg[k][3] == 'flop']
+        favor = [k for k in agg if k.startswith('favor')]
+        # the roofline object: the GEMM that takes most of the step -- except on the FAVOR+ workloads, whose own kernels
+        # (byte-bound streaming over q, k, v) are the path under test: there the slower of favor_fwd / favor_bwd
+        dom = max(favor, key=lambda k: agg[k][1]) if favor else max(gemms, key=lambda k: agg[k][1])
+        roofline = line(dom)
+        # HBM-side bytes per launch of that kernel: measured with rocprofv3 --pmc in runs of their own (FETCH_SIZE and
+        # WRITE_SIZE cannot share a pass, and PMC runs cannot be nested in this one); tools/collect_pmc.sh over this same
+        # command writes the summary, which is used only while it was measured on the kernel sources of this tree.
+        headline = args.workload == 'dislai_b16' and args.band == 20 and B == dbatch
+        tname = 'pmc_gemm_traffic.json' if headline else f'pmc_traffic_{args.workload}.json'
+        tpath = os.path.join(ROOT, 'profiles', tname)
+        traffic, note = None, f'no profiles/{tname}'
+        if os.path.exists(tpath) and (headline or (args.band == 20 and B == dbatch)):
+            from vit_amd.srchash import kernel_source_hash
+            tj = json.load(open(tpath))
+            pmc_names = {'favor_fwd': ['favor_kmax_kernel', 'favor_kv_kernel', 'favor_out_kernel'],
+                         'favor_bwd': ['favor_bwd_q_kernel', 'favor_bwd_kv_kernel']}.get(dom, [dom])
+            if tj.get('kernel_source_sha256') != kernel_source_hash():
+                note = (f'profiles/{tname} was measured on other kernel sources (git {tj.get("git_head", "?")[:10]}): '
+                        'stale, re-run tools/collect_pmc.sh')
+            elif all(k in tj.get('kernels', {}) for k in pmc_names):
+                traffic = sum(tj['kernels'][k]['hbm_bytes_per_launch'] for k in pmc_names)
+                note = f'profiles/{tname}, rocprofv3 --pmc passes at git {tj.get("git_head", "?")[:10]} (+ working tree), same kernel sources'
+            else:
+                note = f'profiles/{tname} has no entry for {pmc_names}'
+        roofline['traffic'] = traffic
+        roofline['traffic_unit'] = 'bytes/launch (PMC)'
+        roofline['traffic_source'] = note
+        if gemms:
+            roofline['all_gemm_tflops'] = sum(agg[k][0] for k in gemms) / sum(agg[k][1] for k in gemms) / 1e12
+            roofline['all_gemm_share_of_step_time'] = sum(agg[k][1] for k in gemms) / elapsed
+        kernels = [line(k) for k in sorted(agg, key=lambda k: -agg[k][1])]
 
     if rank == 0:
         cpu = None
@@ -268,7 +306,7 @@ def main():
             'train_gflop_per_image': fl_img / 1e9, 'model_tflops_per_gpu': model_tflops_gpu,
             'mfma_roofline_frac_per_gpu': model_tflops_gpu / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16
                                                                 else PEAK_F32_TFLOPS),
-            'loss': loss_val, 'roofline': roofline, 'cpu_baseline': cpu,
+            'loss': loss_val, 'roofline': roofline, 'cpu_baseline': cpu, 'timed_kernels': kernels,
         }
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_reducer:

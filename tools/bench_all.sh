@@ -18,4 +18,5 @@ run lai_s16_unmasked --workload lai_s16 --band -1
 run dislai_l16_w8 --workload dislai_l16 --band 8
 run regular_cifar --workload regular_cifar
 run performer_s16_384 --workload performer_s16_384
+run softmax_s16_384 --workload softmax_s16_384
 run disperf_s16 --workload disperf_s16

@@ -11,7 +11,23 @@ from ._lib import F32, BF16, ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU,
 
 # bench.py sets this to a list to collect (kernel, algorithmic flops, start event, end event) per
 # launch: HIP events recorded on the launch stream (torch's current stream) around the kernel.
-KERNEL_TIMER = None
+KERNEL_TIMER = None      # bench.py: a list that receives (name, work, event0, event1, unit) per timed launch
+
+
+def _t0():
+    if KERNEL_TIMER is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _t1(e0, name, work, unit):
+    """work: algorithmic FLOPs (unit 'flop') or algorithmic HBM bytes (unit 'byte') of the launch(es) since _t0()."""
+    if e0 is not None and KERNEL_TIMER is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        KERNEL_TIMER.append((name, float(work), e0, e1, unit))
 
 
 def _dt(t):
@@ -101,20 +117,15 @@ def gemm(a, b, *, trans_a=False, trans_b=True, out=None, out_dtype=None, bias=No
             raise ValueError('gemm: residual shape mismatch')
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous()):
         raise ValueError('gemm: bias must be contiguous fp32 [N]')
-    timer = KERNEL_TIMER
-    if timer is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _t0()
     st = lib().vitk_gemm(_dt(a), _dt(out), int(trans_a), int(trans_b), M, N, K, float(alpha),
                          pa, lda, pb, ldb, pc, ldc, _ptr(bias), act, _ptr(aux_in), _ptr(aux_out), ld_aux,
                          _ptr(residual), ldr, res_period, res_off, grp_rows, grp_stride, grp_off,
                          int(accumulate), splitk, _stream())
     check(st, 'vitk_gemm')
-    if timer is not None:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+    if e0 is not None:
         layout = ('T' if trans_a else 'N') + ('T' if trans_b else 'N')
-        timer.append(('gemm_' + layout + ('_bf16' if a.dtype == torch.bfloat16 else '_f32'), 2.0 * M * N * K, e0, e1))
+        _t1(e0, 'gemm_' + layout + ('_bf16' if a.dtype == torch.bfloat16 else '_f32'), 2.0 * M * N * K, 'flop')
     return out
 
 
@@ -278,10 +289,12 @@ def attn_fwd(qkv_q, qkv_k, qkv_v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, 
     _req_cuda(qkv_q, qkv_k, qkv_v, pk, pq)
     out = torch.empty(B * N, H * dh, device=qkv_q.device, dtype=qkv_q.dtype)
     lse = torch.empty(B, H, N, device=qkv_q.device, dtype=torch.float32)
+    e0 = _t0()
     st = lib().vitk_attn_fwd(_dt(qkv_q), B, H, N, dh, qkv_q.data_ptr(), qkv_k.data_ptr(), qkv_v.data_ptr(), ld,
                              _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
                              out.data_ptr(), H * dh, lse.data_ptr(), float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     check(st, 'vitk_attn_fwd')
+    _t1(e0, 'attn_fwd', 4.0 * B * N * H * dh * out.element_size() + 4.0 * lse.numel(), 'byte')   # q, k, v in, out + lse out
     return out, lse
 
 
@@ -301,6 +314,7 @@ def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, l
         raise ValueError('attn_bwd: workspace too small')
     if not (out.is_contiguous() and dout.is_contiguous()) or out.shape != (B * N, H * dh) or dout.shape != out.shape:
         raise ValueError('attn_bwd: out / dout must be contiguous [B*N, H*dh]')
+    e0 = _t0()
     st = lib().vitk_attn_bwd(_dt(q), B, H, N, dh, q.data_ptr(), k.data_ptr(), v.data_ptr(), ld,
                              _ptr(pk), _ptr(pq), ld_p, float(scale), int(band_w),
                              out.data_ptr(), dout.data_ptr(), H * dh, lse.data_ptr(),
@@ -308,6 +322,7 @@ def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, l
                              _ptr(dpk), _ptr(dpq), H * dh if ld_dp is None else ld_dp, workspace.data_ptr(),
                              float(drop[0]), int(drop[1]), int(drop[2]), _ptr(dbias), _stream())
     check(st, 'vitk_attn_bwd')
+    _t1(e0, 'attn_bwd', 8.0 * B * N * H * dh * out.element_size() + 4.0 * lse.numel(), 'byte')   # q, k, v, out, dout in, dq, dk, dv out
 
 
 def dropout(x, drop, res=None, out=None):
@@ -355,10 +370,12 @@ def favor_fwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, workspace):
     if w.dtype != q.dtype or not w.is_contiguous() or w.shape[1] != dh:
         raise ValueError('favor: w must be contiguous [m, dh] in the compute dtype')
     out = torch.empty(B * L, H * dh, device=q.device, dtype=q.dtype)
+    e0 = _t0()
     st = lib().vitk_favor_fwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(), ld,
                               w.data_ptr(), float(ratio), float(eps), out.data_ptr(), H * dh,
                               workspace.data_ptr(), _stream())
     check(st, 'vitk_favor_fwd')
+    _t1(e0, 'favor_fwd', 4.0 * B * L * H * dh * q.element_size(), 'byte')     # q, k, v read once, out written once
     return out
 
 
@@ -366,10 +383,12 @@ def favor_bwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, out, dout, dq, dk, 
     _req_cuda(q, k, v, w, out, dout, dq, dk, dv, workspace)
     if not (out.is_contiguous() and dout.is_contiguous()) or dout.shape != out.shape:
         raise ValueError('favor_bwd: out / dout must be contiguous [B*L, H*dh]')
+    e0 = _t0()
     st = lib().vitk_favor_bwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(), ld,
                               w.data_ptr(), float(ratio), float(eps), out.data_ptr(), dout.data_ptr(), H * dh,
                               dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ld_d, workspace.data_ptr(), _stream())
     check(st, 'vitk_favor_bwd')
+    _t1(e0, 'favor_bwd', 7.0 * B * L * H * dh * q.element_size(), 'byte')     # q, k, v, dout read, dq, dk, dv written
 
 
 def favor_feature_pitch(m):
@@ -419,10 +438,12 @@ def favor_pos_attn_fwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, pq, pk, wo
         raise ValueError('favor: w must be contiguous [m, dh] in the compute dtype')
     _check_pos_tables(L, H, w.shape[0], pq, pk)
     out = torch.empty(B * L, H * dh, device=q.device, dtype=q.dtype)
+    e0 = _t0()
     st = lib().vitk_favor_pos_attn_fwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                        ld, w.data_ptr(), float(ratio), float(eps), pq.data_ptr(), pk.data_ptr(),
                                        out.data_ptr(), H * dh, workspace.data_ptr(), _stream())
     check(st, 'vitk_favor_pos_attn_fwd')
+    _t1(e0, 'favor_fwd', 4.0 * B * L * H * dh * q.element_size(), 'byte')
     return out
 
 
@@ -434,12 +455,15 @@ def favor_pos_attn_bwd(q, k, v, B, H, L, dh, ld, w, kind, ratio, eps, pq, pk, ou
     _check_pos_tables(L, H, w.shape[0], pq, pk)
     dnq = torch.empty(B, L, H, pq.shape[-1], device=q.device, dtype=torch.float32)
     dnk = torch.empty_like(dnq)
+    e0 = _t0()
     st = lib().vitk_favor_pos_attn_bwd(_dt(q), kind, B, H, L, dh, w.shape[0], q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                        ld, w.data_ptr(), float(ratio), float(eps), pq.data_ptr(), pk.data_ptr(),
                                        out.data_ptr(), dout.data_ptr(), H * dh, dq.data_ptr(), dk.data_ptr(),
                                        dv.data_ptr(), ld_d, dnq.data_ptr(), dnk.data_ptr(), workspace.data_ptr(),
                                        _stream())
     check(st, 'vitk_favor_pos_attn_bwd')
+    # q, k, v, dout read, dq, dk, dv written, plus the two fp32 feature-gradient tables written
+    _t1(e0, 'favor_bwd', 7.0 * B * L * H * dh * q.element_size() + 2.0 * dnq.numel() * 4, 'byte')
     return dnq, dnk
 
 
