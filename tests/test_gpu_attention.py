@@ -28,7 +28,8 @@ def views(qkv, B, N, H, dh):
     return tuple(qkv[:, t * D:(t + 1) * D] for t in range(3))
 
 
-CASES = [(2, 65, 4, 32), (1, 197, 3, 64), (1, 197, 2, 80), (1, 130, 2, 128), (2, 16, 2, 64), (1, 577, 2, 64)]
+CASES = [(2, 65, 4, 32), (1, 197, 3, 64), (1, 197, 2, 80), (1, 130, 2, 128), (2, 16, 2, 64), (1, 577, 2, 64),
+         (2, 130, 3, 72), (1, 208, 2, 80)]      # heads of 72 / 80: whole-head kernels on 80-wide row images
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
@@ -52,7 +53,8 @@ def test_attn_fwd(dtype, bias, w, B, N, H, dh):
     assert relerr(lse, lse_ref) < (1e-5 if dtype == torch.float32 else 2e-3)
 
 
-BWD_CASES = [(2, 65, 4, 32), (1, 197, 3, 64), (1, 197, 2, 80), (2, 16, 2, 64), (1, 300, 2, 64), (3, 130, 2, 128)]
+BWD_CASES = [(2, 65, 4, 32), (1, 197, 3, 64), (1, 197, 2, 80), (2, 16, 2, 64), (1, 300, 2, 64), (3, 130, 2, 128),
+             (2, 130, 3, 72), (1, 208, 2, 80)]
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])

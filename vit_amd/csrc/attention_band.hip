@@ -28,10 +28,12 @@
 
 namespace vitk {
 
-constexpr int BAND_DS_FLOATS = 800;   // per wave: one zero-padded fp32 copy of a dS tile (X or Y layout, attn_common.h)
+constexpr int BAND_DS_ELEMS = 800;    // per wave: one zero-padded bf16 copy of a dS tile (X or Y layout, attn_common.h)
 constexpr int BAND_WAVES = 8;
 constexpr int BAND_THREADS = 64 * BAND_WAVES;
-constexpr int BAND_GC = 2;            // half width of a diagonal group with the bias: 2 * 2 + 1 = 5 diagonals, 96 table rows
+// Half width of a diagonal group with the bias: 2 * 2 + 1 = 5 diagonals, 96 table rows -- or 3 diagonals / 64 rows
+// for a head wider than 64, whose row images leave less of the LDS.
+__host__ __device__ constexpr int band_gc(int DW) { return DW > 64 ? 1 : 2; }
 constexpr int BAND_TPW = 2;           // tiles a wave can own: NT <= 13 tiles over 8 waves
 // The forward holds two row images (K, V), not three: 16 waves' scratch fits, every wave owns ONE query
 // tile (the critical path is one tile's sweep, not two) and four waves per SIMD hide each other's
@@ -62,20 +64,23 @@ struct BandParams {
                             // tokens -- the bias gradient of the fused qkv projection, without a pass over dqkv
 };
 
-template <int DKB, bool BIAS> struct BandCfg {
-    using C = ACfg<__bf16, DKB>;
+template <int DW, bool BIAS> struct BandCfg {
+    static constexpr int DKB = (DW + 31) / 32;     // K blocks of a score product
+    static constexpr int ND = DW / 16;             // 16-wide tiles of the head dim in the outputs
+    using C = ACfg<__bf16, DKB, DW>;
     static constexpr int ASTR = C::ASTR;
+    static constexpr int GC = band_gc(DW);
+    static constexpr int WSCR_BYTES = (BIAS ? 2 * SCR_FLOATS * 4 + BAND_DS_ELEMS * 2 : 0);   // per wave, backward
     static size_t fwd_bytes(int NT, int cmax) {
-        cmax = cmax < BAND_GC ? cmax : BAND_GC;
+        cmax = cmax < GC ? cmax : GC;
         const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
         const int sw = NT < BAND_FWD_WAVES ? NT : BAND_FWD_WAVES;   // waves that own a tile (the rest only stage)
         return rows * ASTR * 2 + (size_t)sw * (BIAS ? 2 * SCR_FLOATS : 0) * 4;
     }
     static size_t bwd_bytes(int NT, int cmax) {
-        cmax = cmax < BAND_GC ? cmax : BAND_GC;
+        cmax = cmax < GC ? cmax : GC;
         const size_t rows = 2 * (size_t)(16 * NT + 16) + (BIAS ? 2 * (size_t)(32 * cmax + 32) : 0);
-        return rows * ASTR * 2 + (size_t)2 * (16 * NT + 16) * 4 +
-               (size_t)BAND_WAVES * ((BIAS ? 2 * SCR_FLOATS : 0) + BAND_DS_FLOATS) * 4 + 3 * 64 * 4;   // + column sums
+        return rows * ASTR * 2 + (size_t)2 * (16 * NT + 16) * 4 + (size_t)BAND_WAVES * WSCR_BYTES + 3 * 16 * ND * 4;   // + column sums
     }
 };
 
@@ -84,9 +89,9 @@ template <int DKB, bool BIAS> struct BandCfg {
 // is one group holding every live diagonal.
 struct BandGroups {
     int cmax, gc, ngroups;
-    __device__ __forceinline__ BandGroups(int w, int NT, bool bias) {
+    __device__ __forceinline__ BandGroups(int w, int NT, bool bias, int gc_max) {
         cmax = w >= 0 ? min((w + 15) / 16, NT - 1) : NT - 1;
-        gc = bias ? min(cmax, BAND_GC) : cmax;
+        gc = bias ? min(cmax, gc_max) : cmax;
         ngroups = (2 * cmax + 1 + 2 * gc) / (2 * gc + 1);
     }
     __device__ __forceinline__ int c_lo(int gi) const { return -cmax + gi * (2 * gc + 1); }
@@ -94,29 +99,31 @@ struct BandGroups {
 };
 
 // relative-table rows of one diagonal group -> LDS (row 0 <-> i - j = 16 c_lo - 15)
-template <int DKB>
+template <int DKB, int DW>
 __device__ __forceinline__ void band_stage_tables(const BandParams& p, __bf16* Pks, __bf16* Pqs, int WR, int c_lo, int h,
                                                   int tid, int nthreads) {
     const __bf16* PK = reinterpret_cast<const __bf16*>(p.pk) + h * p.dh;
     const __bf16* PQ = reinterpret_cast<const __bf16*>(p.pq) + h * p.dh;
     const int r_lo = 16 * c_lo - 15 + (p.N - 1);
-    stage_rows<__bf16, DKB>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, nthreads);
-    stage_rows<__bf16, DKB>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, nthreads);
+    stage_rows<__bf16, DKB, DW>(Pks, PK, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, nthreads);
+    stage_rows<__bf16, DKB, DW>(Pqs, PQ, p.ld_p, r_lo, WR, 0, 2 * p.N - 1, p.dh, tid, nthreads);
 }
 
-template <int DKB, bool BIAS>
+template <int DW, bool BIAS>
 __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const BandParams p) {
     using T = __bf16;
-    using C = ACfg<T, DKB>;
+    using BC = BandCfg<DW, BIAS>;
+    using C = typename BC::C;
+    constexpr int DKB = BC::DKB;
     constexpr int ASTR = C::ASTR;
-    constexpr int ND = 2 * DKB;
+    constexpr int ND = BC::ND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int N = p.N, dh = p.dh;
     const int NT = (N + 15) / 16;
     const int NR = 16 * NT + 16;                       // one zero tile behind the last real one
-    const BandGroups grp(p.w, NT, BIAS);
+    const BandGroups grp(p.w, NT, BIAS, BC::GC);
     const int WR = 32 * grp.gc + 32;
     const int h = blockIdx.x, b = blockIdx.y;
 
@@ -132,8 +139,8 @@ __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const B
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * dh;
 
-    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_FWD_THREADS);
-    stage_rows<T, DKB>(Vs, V, p.ld, 0, NR, 0, N, dh, tid, BAND_FWD_THREADS);
+    stage_rows<T, DKB, DW>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_FWD_THREADS);
+    stage_rows<T, DKB, DW>(Vs, V, p.ld, 0, NR, 0, N, dh, tid, BAND_FWD_THREADS);
 
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const B
         const int c_lo = grp.c_lo(gi), c_hi = grp.c_hi(gi);
         if (BIAS) {
             if (gi > 0) __syncthreads();                      // every wave is done with the previous group's rows
-            band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_FWD_THREADS);
+            band_stage_tables<DKB, DW>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_FWD_THREADS);
         }
         if (BIAS || gi == 0) __syncthreads();
 #pragma unroll
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const B
                     const int kj0 = 16 * kt;
                     Frag<T> kf[DKB];
 #pragma unroll
-                    for (int kb = 0; kb < DKB; ++kb) row_frag<T, DKB>(kf[kb], Ks, kj0, kb, lane);
-                    f32x4 raw = score_tile<T, DKB, BIAS, true>(qf[s], kf, Pks, Pqs, qi0 - kj0 - 16 * c_lo, xs, ys, lane);
+                    for (int kb = 0; kb < DKB; ++kb) row_frag<T, DKB, DW>(kf[kb], Ks, kj0, kb, lane);
+                    f32x4 raw = score_tile<T, DKB, BIAS, true, DW>(qf[s], kf, Pks, Pqs, qi0 - kj0 - 16 * c_lo, xs, ys, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int j = kj0 + 4 * g + r;
@@ -262,19 +269,21 @@ __device__ inline float row16_sum(float t) {
     return t;
 }
 
-template <int DKB, bool BIAS>
+template <int DW, bool BIAS>
 __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandParams p) {
     using T = __bf16;
-    using C = ACfg<T, DKB>;
+    using BC = BandCfg<DW, BIAS>;
+    using C = typename BC::C;
+    constexpr int DKB = BC::DKB;
     constexpr int ASTR = C::ASTR;
-    constexpr int ND = 2 * DKB;
+    constexpr int ND = BC::ND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int N = p.N, dh = p.dh;
     const int NT = (N + 15) / 16;
     const int NR = 16 * NT + 16;
-    const BandGroups grp(p.w, NT, BIAS);
+    const BandGroups grp(p.w, NT, BIAS, BC::GC);
     const int WR = 32 * grp.gc + 32;
     const int h = blockIdx.x, b = blockIdx.y;
 
@@ -286,13 +295,13 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     float* lse2s = reinterpret_cast<float*>(Pqs + (BIAS ? WR * ASTR : 0));
     float* dls = lse2s + NR;
     float* scr = dls + NR;
-    constexpr int WSCR = (BIAS ? 2 * SCR_FLOATS : 0) + BAND_DS_FLOATS;
-    float* xs = scr + wave * WSCR;
+    float* xs = scr + wave * (BC::WSCR_BYTES / 4);
     float* ys = xs + (BIAS ? SCR_FLOATS : 0);
-    float* dsc = ys + (BIAS ? SCR_FLOATS : 0);   // padded dS copy (attn_common.h)
-    float* colacc = scr + BAND_WAVES * WSCR;      // [3][64]: column sums of dQ / dK / dV of this head (p.dbias)
+    T* dsc = reinterpret_cast<T*>(ys + (BIAS ? SCR_FLOATS : 0));   // zero-padded dS copy (attn_common.h), bf16 as the MFMA takes it
+    constexpr int CA = 16 * ND;                                    // floats per matrix in colacc
+    float* colacc = scr + BAND_WAVES * (BC::WSCR_BYTES / 4);       // [3][CA]: column sums of dQ / dK / dV of this head (p.dbias)
     const bool want_bias = p.dbias != nullptr;
-    if (want_bias && tid < 192) colacc[tid] = 0.f;
+    if (want_bias && tid < 3 * CA) colacc[tid] = 0.f;
     // sum over the wave's tiles and its 16 key / query lanes, then one LDS atomic per (group, d)
     auto colsum_acc = [&](const f32x4 (&acc)[BAND_TPW][ND], float* dst) {
 #pragma unroll
@@ -321,23 +330,25 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     const bool drop_on = p.drop.thresh != 0;
     const uint64_t dhead = (uint64_t)(b * p.H + h) * (uint64_t)N;
 
-    stage_rows<T, DKB>(Qs, Q, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
+    stage_rows<T, DKB, DW>(Qs, Q, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
     // dO rows go to LDS and, on the way, delta_i = dO_i . O_i is formed (the CPR lanes of a row
     // each hold one 16-byte chunk of dO and of O): no separate delta kernel, no second read of dO.
-    for (int c = tid; c < NR * C::CPR; c += BAND_THREADS) {
-        const int r = c / C::CPR, ch = c - r * C::CPR;
+    // a row's chunks sit in LG adjacent lanes (LG = CPR rounded up to a power of two; lanes past CPR idle)
+    constexpr int LG = C::CPR <= 4 ? 4 : (C::CPR <= 8 ? 8 : 16);
+    for (int c = tid; c < NR * LG; c += BAND_THREADS) {
+        const int r = c / LG, ch = c - r * LG;
         const int d = ch * C::EPC;
         bf16x8 v = {}, o = {};
         if (r < N && d < dh) {
             v = *reinterpret_cast<const bf16x8*>(dO + (long)r * p.ldo + d);
             o = *reinterpret_cast<const bf16x8*>(O + (long)r * p.ldo + d);
         }
-        *reinterpret_cast<bf16x8*>(dOs + r * ASTR + d) = v;
+        if (ch < C::CPR) *reinterpret_cast<bf16x8*>(dOs + r * ASTR + d) = v;
         float sdot = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) sdot += (float)v[e] * (float)o[e];
 #pragma unroll
-        for (int m = 1; m < C::CPR; m <<= 1) sdot += __shfl_xor(sdot, m, 64);
+        for (int m = 1; m < LG; m <<= 1) sdot += __shfl_xor(sdot, m, 64);
         if (ch == 0) {
             dls[r] = sdot;
             if (r < N) delta[r] = sdot;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
 
     // ---- pass 1: key-stationary, dK^T / dV^T of the wave's key tiles in registers ----------------
     if (BIAS) {   // Y-layout copy: everything outside rows 15..30 stays zero for the whole pass
-        for (int i = lane; i < BAND_DS_FLOATS; i += 64) dsc[i] = 0.f;
+        for (int i = lane; i < BAND_DS_ELEMS / 2; i += 64) reinterpret_cast<uint32_t*>(dsc)[i] = 0u;
     }
     {
         Frag<T> kf[BAND_TPW][DKB], vf[BAND_TPW][DKB];
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
             const int c_lo = grp.c_lo(gi), c_hi = grp.c_hi(gi);
             if (BIAS) {
                 if (gi > 0) __syncthreads();
-                band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_THREADS);
+                band_stage_tables<DKB, DW>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_THREADS);
             }
             if (BIAS || gi == 0) __syncthreads();
 #pragma unroll
@@ -391,10 +402,10 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                             Frag<T> qf[DKB], dof[DKB];
 #pragma unroll
                             for (int kb = 0; kb < DKB; ++kb) {
-                                row_frag<T, DKB>(qf[kb], Qs, qi0, kb, lane);
-                                row_frag<T, DKB>(dof[kb], dOs, qi0, kb, lane);
+                                row_frag<T, DKB, DW>(qf[kb], Qs, qi0, kb, lane);
+                                row_frag<T, DKB, DW>(dof[kb], dOs, qi0, kb, lane);
                             }
-                            const f32x4 raw = score_tile<T, DKB, BIAS, false>(qf, kf[s], Pks, Pqs, rel, xs, ys, lane);
+                            const f32x4 raw = score_tile<T, DKB, BIAS, false, DW>(qf, kf[s], Pks, Pqs, rel, xs, ys, lane);
                             f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                             for (int kb = 0; kb < DKB; ++kb) dp = mma(dof[kb], vf[s][kb], dp);
@@ -414,11 +425,11 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                                 bf16x4{(__bf16)dsv[0], (__bf16)dsv[1], (__bf16)dsv[2], (__bf16)dsv[3]};
                             if (BIAS) {   // dK^T[d][jj] += sum_t Pq^T[d][t] Sy[t][jj]
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) dsc[(15 + 4 * g + r) * DSY_LD + li] = dsv[r];
+                                for (int r = 0; r < 4; ++r) dsc[(15 + 4 * g + r) * DSY_LD + li] = (__bf16)dsv[r];
                                 wave_lds_sync();
                                 Frag<T> sy;   // Sy[t = 8g + e][jj = li] = dS[li + t - 15][li]
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) sy.v[e] = (__bf16)dsc[(li + 8 * g + e) * DSY_LD + li];
+                                for (int e = 0; e < 8; ++e) sy.v[e] = dsc[(li + 8 * g + e) * DSY_LD + li];
 #pragma unroll
                                 for (int dt = 0; dt < ND; ++dt) {
                                     Frag<T> a;
@@ -446,8 +457,8 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
             }
         }
         if (want_bias) {     // tiles / keys past N hold zeros
-            colsum_acc(dkacc, colacc + 64);
-            colsum_acc(dvacc, colacc + 128);
+            colsum_acc(dkacc, colacc + CA);
+            colsum_acc(dvacc, colacc + 2 * CA);
         }
 #pragma unroll
         for (int s = 0; s < BAND_TPW; ++s) {
@@ -471,9 +482,9 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     // ---- K replaces Q in LDS -------------------------------------------------------------------
     __syncthreads();
     if (BIAS) {   // X-layout copy for pass 2: everything outside columns 16..31 stays zero
-        for (int i = lane; i < BAND_DS_FLOATS; i += 64) dsc[i] = 0.f;
+        for (int i = lane; i < BAND_DS_ELEMS / 2; i += 64) reinterpret_cast<uint32_t*>(dsc)[i] = 0u;
     }
-    stage_rows<T, DKB>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
+    stage_rows<T, DKB, DW>(Ks, K, p.ld, 0, NR, 0, N, dh, tid, BAND_THREADS);
 
     // ---- pass 2: query-stationary, dQ^T of the wave's query tiles in registers (lane = query) ----
     // dS is NOT recomputed: pass 1 left every live tile in the workspace (same workgroup, visible
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
             const int c_lo = grp.c_lo(gi), c_hi = grp.c_hi(gi);
             if (BIAS && grp.ngroups > 1) {   // a single group's rows are still in place from pass 1
                 if (gi > 0) __syncthreads();
-                band_stage_tables<DKB>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_THREADS);
+                band_stage_tables<DKB, DW>(p, Pks, Pqs, WR, c_lo, h, tid, BAND_THREADS);
             }
             if ((BIAS && grp.ngroups > 1) || gi == 0) __syncthreads();
 #pragma unroll
@@ -510,11 +521,12 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                             for (int r = 0; r < 4; ++r) dsv[r] = (float)e[4 * r];
                             if (BIAS) {   // dQ^T[d][ii] += sum_t Pk^T[d][t] Sx[t][ii]
                                 const int rel = qi0 - 16 * kt - 16 * c_lo;
-                                *reinterpret_cast<f32x4*>(dsc + li * DSX_LD + 16 + 4 * g) = dsv;
+                                *reinterpret_cast<bf16x4*>(dsc + li * DSX_LD + 16 + 4 * g) =
+                                    bf16x4{(__bf16)dsv[0], (__bf16)dsv[1], (__bf16)dsv[2], (__bf16)dsv[3]};
                                 wave_lds_sync();
                                 Frag<T> sx;   // Sx[t = 8g + e][ii = li] = dS^T[li][li + 15 - t]
 #pragma unroll
-                                for (int ee = 0; ee < 8; ++ee) sx.v[ee] = (__bf16)dsc[li * (DSX_LD + 1) + 31 - 8 * g - ee];
+                                for (int ee = 0; ee < 8; ++ee) sx.v[ee] = dsc[li * (DSX_LD + 1) + 31 - 8 * g - ee];
 #pragma unroll
                                 for (int dt = 0; dt < ND; ++dt) {
                                     Frag<T> a;
@@ -557,8 +569,8 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
     }
     if (want_bias) {     // one contiguous 256-byte atomic per matrix and head
         __syncthreads();
-        if (tid < 192) {
-            const int which = tid >> 6, d = tid & 63;
+        if (tid < 3 * CA) {
+            const int which = tid / CA, d = tid - which * CA;
             if (d < dh) atomicAdd(p.dbias + (long)which * p.H * dh + h * dh + d, colacc[tid]);
         }
     }
@@ -566,31 +578,35 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
 
 // ------------------------------------------------------------------------------------------- host
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w) {
-    if (dtype != VITK_BF16 || N > 208 || dh > 64 || dh % 8 != 0) return false;
+    if (dtype != VITK_BF16 || N > 208 || dh > 80 || dh % 8 != 0) return false;
     (void)bias;
     (void)band_w;   // any band, with or without the bias (diagonal groups)
     return true;
 }
+// every instantiation fits the 160 KiB of a CU at the largest head it is dispatched for (13 tiles, full diagonal groups)
+static_assert(2 * 224 * 88 * 2 + 2 * 64 * 88 * 2 + 13 * 2 * SCR_FLOATS * 4 <= 160 * 1024, "forward, 80-wide head");
+static_assert(2 * 224 * 88 * 2 + 2 * 64 * 88 * 2 + 2 * 224 * 4 + BAND_WAVES * (2 * SCR_FLOATS * 4 + BAND_DS_ELEMS * 2) + 3 * 80 * 4 <= 160 * 1024, "backward, 80-wide head");
+static_assert(2 * 224 * 72 * 2 + 2 * 96 * 72 * 2 + 2 * 224 * 4 + BAND_WAVES * (2 * SCR_FLOATS * 4 + BAND_DS_ELEMS * 2) + 3 * 64 * 4 <= 160 * 1024, "backward, 64-wide head");
 
-template <int DKB, bool BIAS> static void band_fwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
-    const size_t lds = BandCfg<DKB, BIAS>::fwd_bytes(NT, cmax);
+template <int DW, bool BIAS> static void band_fwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
+    const size_t lds = BandCfg<DW, BIAS>::fwd_bytes(NT, cmax);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_band_kernel<DKB, BIAS>,
+        (void)hipFuncSetAttribute((const void*)attn_fwd_band_kernel<DW, BIAS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((attn_fwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(BAND_FWD_THREADS), lds, st, p);
+    hipLaunchKernelGGL((attn_fwd_band_kernel<DW, BIAS>), dim3(p.H, p.B), dim3(BAND_FWD_THREADS), lds, st, p);
 }
-template <int DKB, bool BIAS> static void band_bwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
-    const size_t lds = BandCfg<DKB, BIAS>::bwd_bytes(NT, cmax);
+template <int DW, bool BIAS> static void band_bwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
+    const size_t lds = BandCfg<DW, BIAS>::bwd_bytes(NT, cmax);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_band_kernel<DKB, BIAS>,
+        (void)hipFuncSetAttribute((const void*)attn_bwd_band_kernel<DW, BIAS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    hipLaunchKernelGGL((attn_bwd_band_kernel<DKB, BIAS>), dim3(p.H, p.B), dim3(BAND_THREADS), lds, st, p);
+    hipLaunchKernelGGL((attn_bwd_band_kernel<DW, BIAS>), dim3(p.H, p.B), dim3(BAND_THREADS), lds, st, p);
 }
 
 void band_launch(const BandParams& p, bool backward, hipStream_t st) {
@@ -598,16 +614,17 @@ void band_launch(const BandParams& p, bool backward, hipStream_t st) {
     int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
     if (cmax > NT - 1) cmax = NT - 1;
     const bool bias = p.pk != nullptr;
-    const int dkb = (p.dh + 31) / 32;
 #define VITK_BAND(D, BI)                                          \
     do {                                                          \
         if (backward) band_bwd_launch<D, BI>(p, NT, cmax, st);    \
         else band_fwd_launch<D, BI>(p, NT, cmax, st);             \
     } while (0)
-    if (dkb == 1) {
-        if (bias) VITK_BAND(1, true); else VITK_BAND(1, false);
-    } else {
-        if (bias) VITK_BAND(2, true); else VITK_BAND(2, false);
+    if (p.dh <= 32) {
+        if (bias) VITK_BAND(32, true); else VITK_BAND(32, false);
+    } else if (p.dh <= 64) {
+        if (bias) VITK_BAND(64, true); else VITK_BAND(64, false);
+    } else {      // heads of 72 / 80 (ViT-L/16's 1280 / 16): 80-wide row images, the last K block half empty
+        if (bias) VITK_BAND(80, true); else VITK_BAND(80, false);
     }
 #undef VITK_BAND
 }

@@ -1011,7 +1011,8 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
         if (pk) {
             const int dkb = (dh + 31) / 32;
             if (dkb == 1) relds_launch<1>(p, zgroups, stream);
-            else relds_launch<2>(p, zgroups, stream);
+            else if (dkb == 2) relds_launch<2>(p, zgroups, stream);
+            else relds_launch<3>(p, zgroups, stream);
         }
         VITK_CHECK_LAUNCH("vitk_attn_bwd");
         return VITK_OK;

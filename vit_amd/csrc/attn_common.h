@@ -38,9 +38,13 @@ constexpr int DSY_LD = 17;
 constexpr int DSY_ELEMS = 47 * DSY_LD;     // 799
 constexpr int DSXY_ELEMS = 1568;           // X copy + Y copy of one tile, rounded up to 4 bytes
 
-template <typename T, int DKB> struct ACfg {
+// DW: width of an LDS row image in elements.  32 * DKB by default; the whole-head kernels stage a head of 80 as
+// DW = 80 (DKB = 3): the last K block is half there, row_frag zeroes the other half in registers, and the LDS the
+// 16 missing columns would take is what lets the 197-token images of such a head fit (attention_band.hip).
+template <typename T, int DKB, int DW = 32 * DKB> struct ACfg {
+    static_assert(DW <= 32 * DKB && DW > 32 * (DKB - 1) && DW % 16 == 0, "row image width vs K blocks");
     static constexpr int EPC = 16 / sizeof(T);
-    static constexpr int DP = 32 * DKB;                 // head dim padded to the MFMA K block
+    static constexpr int DP = DW;                       // head dim padded to the staged width
     static constexpr int ASTR = DP + 16 / sizeof(T);    // LDS row stride (elements): +16 B de-conflicts banks
     static constexpr int CPR = DP / EPC;                // 16-byte chunks per row
 };
@@ -50,10 +54,10 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 
 // Stage `nrows` rows x DP columns into LDS.  Row r of the tile is global row (grow0 + r) of a
 // matrix with leading dimension ld; rows outside [lo, hi) and columns >= dh are zero-filled.
-template <typename T, int DKB>
+template <typename T, int DKB, int DW = 32 * DKB>
 __device__ __forceinline__ void stage_rows(T* lds, const T* __restrict__ g, long ld, int grow0, int nrows,
                                            int lo, int hi, int dh, int tid, int nthreads) {
-    using C = ACfg<T, DKB>;
+    using C = ACfg<T, DKB, DW>;
     const int total = nrows * C::CPR;
     for (int c = tid; c < total; c += nthreads) {
         const int r = c / C::CPR, ch = c - r * C::CPR;
@@ -66,9 +70,10 @@ __device__ __forceinline__ void stage_rows(T* lds, const T* __restrict__ g, long
 }
 
 // Row fragment (K-contiguous): tile rows [row_base, +16), head-dim block kb.
-template <typename T, int DKB>
+template <typename T, int DKB, int DW = 32 * DKB>
 __device__ __forceinline__ void row_frag(Frag<T>& f, const T* lds, int row_base, int kb, int lane) {
-    frag_load(f, lds + (row_base + (lane & 15)) * ACfg<T, DKB>::ASTR + 32 * kb + 8 * (lane >> 4));
+    frag_load(f, lds + (row_base + (lane & 15)) * ACfg<T, DKB, DW>::ASTR + 32 * kb + 8 * (lane >> 4));
+    if (DW < 32 * DKB && 32 * kb + 8 * (lane >> 4) >= DW) frag_zero(f);   // past the image: pad / the next row, not data
 }
 
 // Row fragment straight from global memory (the block's own 16 rows, read once).
@@ -127,7 +132,7 @@ __device__ __forceinline__ void acc_to_frag(Frag<float>& f, const f32x4& a, cons
 //             false -> result[r] = raw[query 4g+r][key l&15]   (lane owns a key)
 //   pk / pq : staged band tiles; `rel` = band row of delta0 = i0 - j0 - 15 for this tile pair
 //   xs / ys : this wave's skew scratch (SCR_FLOATS each)
-template <typename T, int DKB, bool BIAS, bool TRANS>
+template <typename T, int DKB, bool BIAS, bool TRANS, int DW = 32 * DKB>
 __device__ __forceinline__ f32x4 score_tile(const Frag<T> (&qf)[DKB], const Frag<T> (&kf)[DKB], const T* pk,
                                             const T* pq, int rel, float* xs, float* ys, int lane) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -141,9 +146,9 @@ __device__ __forceinline__ f32x4 score_tile(const Frag<T> (&qf)[DKB], const Frag
 #pragma unroll
             for (int kb = 0; kb < DKB; ++kb) {
                 Frag<T> a;
-                row_frag<T, DKB>(a, pk, rel + 16 * u, kb, lane);
+                row_frag<T, DKB, DW>(a, pk, rel + 16 * u, kb, lane);
                 x = mma(a, qf[kb], x);   // X^T[t = 16u + 4g + r][ii = l&15]
-                row_frag<T, DKB>(a, pq, rel + 16 * u, kb, lane);
+                row_frag<T, DKB, DW>(a, pq, rel + 16 * u, kb, lane);
                 y = mma(a, kf[kb], y);   // Y^T[t][jj = l&15]
             }
             *reinterpret_cast<f32x4*>(xs + li * SCR_LD + 16 * u + 4 * g) = x;
