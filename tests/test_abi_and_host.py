@@ -120,3 +120,21 @@ def test_flop_model_matches_survey_table():
     assert abs(f - 360.7) < 0.5
     f = bench.train_flops_per_image('transformer_timm_lai', PRESETS['S'], 197, 16, 1000, 128, 20) / 1e9
     assert abs(f - 101.9) < 0.3
+
+
+def test_gemm_async_epilogue_loads_are_never_spilled(tmp_path):
+    """The GEMM's fast epilogue loads its side operands from inline asm and waits by hand; a register allocator that
+    spills such a register before the wait corrupts whatever reuses it (tools/check_async_loads.py).  Compile the
+    kernel file to assembly and check every kernel in it."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc here')
+    from vit_amd import _build
+    asm = tmp_path / 'gemm256.s'
+    src = os.path.join(ROOT, 'vit_amd', 'csrc', 'gemm256.hip')
+    subprocess.run([hipcc, *_build.FLAGS, '--cuda-device-only', '-S', src, '-o', str(asm)], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_async_loads.py'), str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]

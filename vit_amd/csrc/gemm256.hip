@@ -221,7 +221,8 @@ __device__ __forceinline__ void epi8_regs(const GemmParams& p, long row, int n8,
 
 // The wave's 128 x 64 block.  ONE rolled loop over its eight 16-row tiles (only the register
 // selection is per tile): unrolled, the fused epilogue is ~0.5 MiB of straight-line code per kernel.
-template <typename TC>
+// ALLOW_FAST = false: only the split-K and the rolled generic forms (no hand-counted asynchronous loads).
+template <typename TC, bool ALLOW_FAST = true>
 __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&acc)[8][4], float* wl, int mrow0, int n0w,
                                             int split, int lane) {
     const int g = lane >> 4, lm = lane & 15;
@@ -258,8 +259,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
     const bool odd = (p.residual != nullptr && (p.act == ACT_DGELU || p.act == ACT_DRELU)) ||   // two side operands
                      (p.residual != nullptr && p.act == ACT_GELU && p.aux_out != nullptr) || p.accumulate;
     // fast form: the wave's whole 128 x 64 block is inside the matrix, 16-byte accesses are legal
-    const bool fast = p.c_vec8_ok && n0w + 64 <= p.N && mrow0 + 128 <= p.M && p.grp_rows == 0 && p.res_period == 0 && !odd;
-    if (fast) {
+    const bool fast = ALLOW_FAST && p.c_vec8_ok && n0w + 64 <= p.N && mrow0 + 128 <= p.M && p.grp_rows == 0 && p.res_period == 0 && !odd;
+    if (ALLOW_FAST && fast) {
         // Straight-line code with hand-counted waits.  Issue order per wave:
         //   [4 bias loads] S(0) | S(1) wait(2) stores(0) | S(2) wait(ns + 2) stores(1) | ... | wait(ns) stores(7)
         // S(i) = the two 16-byte side loads of row tile i, ns = stores per row tile: every wait leaves
@@ -654,7 +655,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #ifdef VITK_GEMM_STAMPS
             if (tl && tl_r < 10) tls[2 + 3 * tl_r] = __builtin_amdgcn_s_memtime();
 #endif
-            epilogue256<TC>(p, acc, wl, me.m0 + wm * 128, me.n0 + wn * 64, me.split, lane);
+            // The fast form's loads come from inline asm and are waited for by hand: the compiler takes their registers for
+            // valid at once, and a spill in between stores data that has not landed and hands the register on (the load
+            // then lands on the new owner -- seen as a wild pointer and a GPU fault when unrelated code raised the
+            // pressure).  tools/check_async_loads.py reads the generated assembly for exactly that (a CPU test runs it);
+            // it found the bias loads of the K-major-A instances spilled that way.  Those are the dW GEMMs, always
+            // split-K in the layer: they do not carry the fast form (which also takes them from ~28 spilled VGPRs to 2).
+            epilogue256<TC, !A_KM>(p, acc, wl, me.m0 + wm * 128, me.n0 + wn * 64, me.split, lane);
             VITK_STAMP(22);
 #ifdef VITK_GEMM_STAMPS
             if (tl && tl_r < 10) {

@@ -9,6 +9,7 @@ type: fp32 runs the exact f32 MFMA path (parity to 1e-5), bf16 keeps a bf16 shad
 (refreshed when the parameter's version counter moves) and bf16 activations with fp32
 accumulation, statistics, softmax, bias, LayerNorm affine and all parameter gradients.
 """
+import os
 import weakref
 
 import torch
@@ -149,11 +150,52 @@ def grad_slot(param):
     return None
 
 
-def _dw(dy, x, out=None):
+# ---- the weight-gradient GEMMs of a fused block run on a second stream ------------------------------------------
+# A layer's dX GEMMs are a dependent chain; its dW GEMMs hang off that chain and nothing in the layer reads them.
+# Every GEMM here is a persistent launch of one workgroup per CU whose last round of tiles leaves CUs idle (396
+# tiles of 256 x 256 on 256 CUs: the second round is 55 % full).  With the dW GEMMs on a stream of their own the
+# hardware starts their workgroups on whatever CUs the dX launch has let go of, and the other way round.
+# Lifetimes: the operands of a pending dW GEMM are kept referenced until side_join(), which every fused backward
+# calls before it returns (the main stream then waits for the side stream), so neither the caching allocator nor
+# the per-model scratch buffers (_ext_workspace) can hand their memory to a later main-stream kernel too early.
+SIDE_DW = os.environ.get('VITK_SIDE_DW', '1') != '0'
+_side_streams = {}
+_side_pending = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def side_join(device):
+    """Main stream waits for the dW GEMMs queued on the side stream since the last join."""
+    keep = _side_pending.get(device)
+    if keep:
+        ev = torch.cuda.Event()
+        ev.record(_side_stream(device))
+        torch.cuda.current_stream(device).wait_event(ev)
+        keep.clear()
+
+
+def _dw(dy, x, out=None, side=False):
     """dW[out, in] = dy^T x in fp32 (split-K over the token dimension).  ``out``: a ZEROED fp32 buffer to
     add into (a slice of the block's one zero-filled pool: the split-K atomics then need no memset of
-    their own -- four 6 us fills per block become part of one)."""
+    their own -- four 6 us fills per block become part of one).  ``side``: queue it on the side stream (the
+    caller must side_join() before anything reads ``out`` or its operands' memory is released)."""
     if out is not None and dy.dtype == torch.bfloat16:
+        if side and SIDE_DW and not torch.cuda.is_current_stream_capturing():
+            dev = dy.device
+            st = _side_stream(dev)
+            ev = torch.cuda.Event()
+            ev.record()                       # dy, x and the zero fill of ``out`` are queued before this point
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True)
+            _side_pending.setdefault(dev, []).append((dy, x, out))
+            return out
         return ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True)
     return ops.gemm(dy, x, trans_a=True, trans_b=False, out_dtype=torch.float32)
 
@@ -377,10 +419,10 @@ def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad, db1=None, db2=None, d
     _, bwd_code = _act_codes(act)
     if not db2_done:
         db2 = ops.colsum(dy, out=db2)
-    dw2 = _dw(dy, hmid, out=dw2)
+    dw2 = _dw(dy, hmid, out=dw2, side=True)
     dpre = _dx(dy, w2, act=bwd_code, aux_in=pre if act == 'gelu' else hmid)
     db1 = ops.colsum(dpre, out=db1)
-    dw1 = _dw(dpre, x, out=dw1)
+    dw1 = _dw(dpre, x, out=dw1, side=True)
     dx = _dx(dpre, w1, residual=residual_grad)
     return dx, dw1, db1, dw2, db2
 
@@ -429,17 +471,18 @@ class PreLNBlockFn(torch.autograd.Function):
                                            dw2=s_w2 if s_w2 is not None else zp.take(D, F))
         dg2, dbe2, dbproj = zp.take(D), zp.take(D), zp.take(D)
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, _f32(g2), dg2, dbe2, add=dy, dxsum=dbproj)
-        dwproj = _dw(dx1, attn, out=s_wproj if s_wproj is not None else zp.take(D, D))
+        dwproj = _dw(dx1, attn, out=s_wproj if s_wproj is not None else zp.take(D, D), side=True)
         dattn = _dx(dx1, wproj)
         dbqkv = zp.take(3 * D) if ctx.has_qkv_bias else None        # summed by the attention backward itself
         dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse, dbias=dbqkv)
-        dwqkv = _dw(dqkv, h1, out=s_wqkv if s_wqkv is not None else zp.take(3 * D, D))
+        dwqkv = _dw(dqkv, h1, out=s_wqkv if s_wqkv is not None else zp.take(3 * D, D), side=True)
         # a fresh alias of a slab view: autograd adopts it as .grad without a copy
         dw1, dw2, dwproj, dwqkv = (t.detach() if t is s else t
                                    for t, s in ((dw1, s_w1), (dw2, s_w2), (dwproj, s_wproj), (dwqkv, s_wqkv)))
         dh1 = _dx(dqkv, wqkv)
         dg1, dbe1 = zp.take(D), zp.take(D)
         dx = ops.layernorm_bwd(dh1, x, mean1, rstd1, _f32(g1), dg1, dbe1, add=dx1)
+        side_join(x.device)
         return dx, dg1, dbe1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbe2, dw1, db1, dw2, db2, None
 
 
@@ -553,7 +596,7 @@ class DisLayerFn(torch.autograd.Function):
         ds1_ext = _ext_workspace('ds1', ME, D, dt, x_ext.device, (M1, R)) if band is not None else \
             torch.empty(ME, D, device=x_ext.device, dtype=dt)
         ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
-        dwo = _dw(ds1, attn, out=s_wo if s_wo is not None else zp.take(D, D))
+        dwo = _dw(ds1, attn, out=s_wo if s_wo is not None else zp.take(D, D), side=True)
         if dwo is s_wo:
             dwo = dwo.detach()
         dattn = _dx(ds1, wo)
@@ -569,8 +612,9 @@ class DisLayerFn(torch.autograd.Function):
         if band is not None:
             dqkv_ext[M1:M1 + R, :2 * D].copy_(dtab)               # (dPq | dPk) in compute dtype
             ops.colsum(dtab, out=dbqkv[:2 * D])                   # the table rows went through the same projections
-        dwqkv = _dw(dqkv_ext, x_ext, out=zp.take(3 * D, D))
+        dwqkv = _dw(dqkv_ext, x_ext, out=zp.take(3 * D, D), side=True)
         dx_ext = _dx(dqkv_ext, (wq, wk, wv), residual=ds1_ext)
+        side_join(x_ext.device)
         dx = dx_ext[:M1]
         dband = dx_ext[M1:M1 + R] if band is not None else None
         dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
