@@ -33,6 +33,17 @@ extern "C" {
 int vitk_version(void);
 const char* vitk_last_error(void);
 
+/* Zero fills under HIP graph capture.  Entry points that accumulate with atomics (vitk_gemm with split-K or
+ * accumulate, vitk_attn_bwd's table gradients, vitk_colsum, the FAVOR+ state) need their targets zeroed first; where the
+ * library does that itself it launches a kernel of its own (vitk_zero_async in csrc/runtime.hip), never hipMemsetAsync.
+ * Reason: with hipMemsetAsync nodes in a training step captured by torch.cuda.graph (ROCm 7.2, PyTorch 2.10), the
+ * second replay accumulated onto stale data (logits 5e36); the same step with kernel zero fills replays bit-stably.
+ * The cause was not isolated: tools/micro/memset_graph.hip captures hundreds of (memset, accumulate, check) triples
+ * with plain HIP -- hipMemsetAsync on large, tiny and pitched targets, hipMemsetD32Async -- and every replay is correct, so
+ * memset nodes as such are not broken; the failure needed the torch capture (its private memory pool and capture mode)
+ * around ctypes calls.  A caller that captures these entry points and zeroes the accumulation targets itself should do it
+ * with a kernel (torch's zero_() is one) rather than a memset node, or verify two replays against eager as
+ * tests/test_gpu_graph.py does. */
 /* C = epilogue(alpha * op(A) op(B) + bias) [+ residual]      (MFMA, fp32 accumulate)
  * Replaces nn.Linear forward/backward everywhere on the path: qkv / proj / Mlp fc1,fc2
  * (timm_classes/timm_locality_aware_transformer.py:48,77,94), query/key/value_proj,
