@@ -16,7 +16,8 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # fp32: 2e-5 max-norm (the feature maps exponentiate: 1e-5 is borderline for single elements).
 # bf16: FAVOR+ is discontinuous in its inputs (ReLU gates, the argmax that receives the max
 # gradient), so merely ROUNDING q/k/v/w to bf16 and running the fp32 oracle already moves single
-# gradient elements by 1-10 % (tools/favor_err.py prints that floor).  The bf16 bar is therefore
+# gradient elements by 1-10 % (tests/test_favor_floor.py asserts that floor on the oracle alone;
+# tools/favor_err.py prints it next to the kernels' errors).  The bf16 bar is therefore
 # relative L2 <= 3e-2 (the floor is 1-2e-2) with a loose 0.2 max-norm guard; whole modules (the
 # qkv activations are rounded to bf16 as well, and m = 16 features flip more weight per gate) get
 # 5e-2 (measured 3.1-3.9e-2 on the two worst gradients, <= 2e-2 on every output).
