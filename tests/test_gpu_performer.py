@@ -13,7 +13,7 @@ from oracle import ref_cpu as R
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-# fp32: 2e-5 max-norm (the feature maps exponentiate: 1e-5 is borderline for single elements).
+# fp32: 1e-5 max-norm, the bar of every other fp32 kernel (measured 2-3e-6 on outputs and gradients).
 # bf16: FAVOR+ is discontinuous in its inputs (ReLU gates, the argmax that receives the max
 # gradient), so merely ROUNDING q/k/v/w to bf16 and running the fp32 oracle already moves single
 # gradient elements by 1-10 % (tests/test_favor_floor.py asserts that floor on the oracle alone;
@@ -21,7 +21,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # relative L2 <= 3e-2 (the floor is 1-2e-2) with a loose 0.2 max-norm guard; whole modules (the
 # qkv activations are rounded to bf16 as well, and m = 16 features flip more weight per gate) get
 # 5e-2 (measured 3.1-3.9e-2 on the two worst gradients, <= 2e-2 on every output).
-TOL = {torch.float32: 2e-5, torch.bfloat16: 3e-2}
+TOL = {torch.float32: 1e-5, torch.bfloat16: 3e-2}
 MODULE_SCALE = {torch.float32: 1.0, torch.bfloat16: 5.0 / 3.0}
 DTYPES = [torch.float32, torch.bfloat16]
 IDS = ['f32', 'bf16']
