@@ -149,7 +149,7 @@ def main():
     ap.add_argument('--cpu-layers', type=int, default=24)
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--graph', action='store_true',
-                    help='1 GPU: replay the step as one captured HIP graph (vit_amd.graph; the per-GEMM timer is off)')
+                    help='replay the step as one captured HIP graph, gradient exchange included (vit_amd.graph; the per-GEMM timer is off)')
     ap.add_argument('--force-reducer', action='store_true',
                     help='diagnostic: run the gradient reducer (flat slabs, hooks, all-reduce) even at world size 1')
     args = ap.parse_args()
@@ -184,7 +184,7 @@ def main():
     net = build_model(variant, preset, img_size=img, patch_size=patch, num_classes=classes,
                       mask_epochs=MASK_EPOCHS if 'lai' in variant else None, dtype=dtype, device=dev)
     from vit_amd.optim import AdamW
-    use_graph = args.graph and world == 1 and not args.force_reducer
+    use_graph = args.graph          # with a reducer the RCCL exchange is captured too (vit_amd.graph)
     opt = AdamW(net.parameters(), lr=1e-4, capturable=use_graph)
     reducer = None
     if world > 1 or args.force_reducer:
@@ -205,7 +205,7 @@ def main():
 
     if use_graph:
         from vit_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(net, opt, x, y, epoch=epoch, warmup=max(2, args.warmup))
+        graphed = GraphedTrainStep(net, opt, x, y, epoch=epoch, warmup=max(2, args.warmup), reducer=reducer)
         step_fn = lambda: graphed.step(x, y)      # noqa: E731
         args.no_kernel_timer = True
     else:

@@ -41,3 +41,35 @@ def test_reducer_nccl_world1_matches_plain():
             assert torch.allclose(p.float(), q.float(), atol=5e-3, rtol=5e-2), n
     finally:
         dist.destroy_process_group()
+
+
+def test_graph_captures_the_gradient_exchange():
+    """The whole step INCLUDING the reducer's RCCL all-reduces as one HIP graph (always_reduce: the collectives are
+    issued at world size 1 too, on RCCL's stream, through async handles -- the launch structure of an N-GPU step):
+    replays follow the eager trajectory."""
+    from vit_amd.ddp import GradReducer
+    from vit_amd.graph import GraphedTrainStep
+    from vit_amd.optim import AdamW
+    from vit_amd.train import build_model, train_step
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29900 + os.getpid() % 90), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        kw = dict(img_size=32, patch_size=4, num_classes=10, dtype=torch.bfloat16, depth=2)
+        torch.manual_seed(0)
+        ref = build_model('disentangled_lai_attention', 'cifar', **kw)
+        net = build_model('disentangled_lai_attention', 'cifar', **kw)
+        net.load_state_dict(ref.state_dict())
+        x = torch.randn(16, 3, 32, 32, device='cuda')
+        y = torch.randint(0, 10, (16,), device='cuda')
+        o_ref = AdamW(ref.parameters(), lr=1e-3)
+        o_net = AdamW(net.parameters(), lr=1e-3, capturable=True)
+        red = GradReducer(net, bucket_mb=1, always_reduce=True)
+        g = GraphedTrainStep(net, o_net, x, y, epoch=0, warmup=2, reducer=red)
+        assert len(red.buckets) > 1
+        eager = [float(train_step(ref, o_ref, x, y, 0)) for _ in range(6)]
+        graphed = [float(g.step(x, y)) for _ in range(4)]          # steps 3..6 (two warm-up steps ran eagerly)
+        for a, b in zip(eager[2:], graphed):
+            assert abs(a - b) < 2e-2 * max(1.0, abs(a)), (eager, graphed)
+        assert graphed[-1] < eager[0]
+    finally:
+        dist.destroy_process_group()

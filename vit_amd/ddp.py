@@ -26,7 +26,8 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, module, bucket_mb=128, process_group=None, broadcast=True, comm_dtype=torch.float32):
+    def __init__(self, module, bucket_mb=128, process_group=None, broadcast=True, comm_dtype=torch.float32,
+                 always_reduce=False):
         if not dist.is_initialized():
             raise RuntimeError('GradReducer needs torch.distributed to be initialised')
         self.group = process_group
@@ -48,6 +49,9 @@ class GradReducer:
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError('GradReducer: comm_dtype must be torch.float32 or torch.bfloat16')
         self.comm_dtype = comm_dtype
+        # always_reduce: issue the collectives at world size 1 too (they are copies there): lets one GPU rehearse the whole
+        # exchange -- RCCL's stream, the async handles, their capture into a HIP graph -- as a run on N GPUs would do it
+        self.always_reduce = bool(always_reduce)
         self._stage = {}
         if broadcast and self.world > 1:
             self.broadcast_parameters(module)
@@ -116,7 +120,7 @@ class GradReducer:
 
     def _launch(self, bi):
         self._launched[bi] = True
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             flat = self.buckets[bi]
             if self.comm_dtype != torch.float32:
                 stage = self._stage.get(bi)

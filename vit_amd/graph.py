@@ -8,7 +8,11 @@ synchronises or reads device memory on the host, so the whole step -- forward, l
 with its weight copies -- captures into one graph; the only values that change between replays
 (AdamW's bias corrections and learning rate) live in device memory (vitk_adamw_dyn).
 
-Single GPU only: the RCCL gradient exchange of vit_amd.ddp is not captured.
+Data parallel: with ``reducer`` (vit_amd.ddp.GradReducer, built by the eager warm-up steps) the gradient exchange is
+part of the graph -- the hooks' bucket all-reduces are RCCL launches on RCCL's stream, forked from and joined to the
+capturing stream by events, all of which a stream capture records; the .grad views into the flat slabs, the AdamW
+launch tables over them and the bucket layout are fixed after the first step, so every replay runs the same exchange.
+Every rank must capture and replay in step (a collective inside a graph is still a collective).
 """
 import torch
 
@@ -23,7 +27,7 @@ class GraphedTrainStep:
     build another GraphedTrainStep when the stage changes (four times in a training run).
     """
 
-    def __init__(self, net, optimizer, img, target, epoch=None, smoothing=0.1, warmup=3):
+    def __init__(self, net, optimizer, img, target, epoch=None, smoothing=0.1, warmup=3, reducer=None):
         if not isinstance(optimizer, AdamW) or not optimizer.capturable:
             raise ValueError('GraphedTrainStep needs vit_amd.optim.AdamW(capturable=True)')
         from . import dropout as VD
@@ -31,6 +35,9 @@ class GraphedTrainStep:
             raise ValueError('GraphedTrainStep: dropout is active (p > 0 in training mode); a captured graph bakes the '
                              'dropout streams into its kernel arguments and every replay would repeat the same masks')
         self.net, self.optimizer, self.epoch, self.smoothing = net, optimizer, epoch, smoothing
+        self.reducer = reducer
+        if reducer is not None and warmup < 2:
+            raise ValueError('GraphedTrainStep: the reducer builds its buckets on the first eager step; warmup >= 2')
         self.img = img.clone()
         self.target = target.clone()
         # warm-up on a side stream (weight copies, optimizer state, kernel attributes all get created eagerly)
@@ -39,14 +46,14 @@ class GraphedTrainStep:
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 optimizer.update_dyn()
-                train_step(net, optimizer, self.img, self.target, epoch, smoothing)
+                train_step(net, optimizer, self.img, self.target, epoch, smoothing, reducer=reducer)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.update_dyn()
         torch.cuda.synchronize()
         with torch.cuda.graph(self.graph):
-            self.loss = train_step(net, optimizer, self.img, self.target, epoch, smoothing)
+            self.loss = train_step(net, optimizer, self.img, self.target, epoch, smoothing, reducer=reducer)
         # the capture itself executed nothing: that step's dyn values are consumed by the first replay
         self._pending = True
 
