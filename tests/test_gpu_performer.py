@@ -22,7 +22,9 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # qkv activations are rounded to bf16 as well, and m = 16 features flip more weight per gate) get
 # 5e-2 (measured 3.1-3.9e-2 on the two worst gradients, <= 2e-2 on every output).
 TOL = {torch.float32: 1e-5, torch.bfloat16: 3e-2}
-MODULE_SCALE = {torch.float32: 1.0, torch.bfloat16: 5.0 / 3.0}
+# fp32 modules (projection GEMMs around the FAVOR+ kernels, split-K atomics in their gradients): the worst element
+# sits AT 1e-5 (1.00014e-5 seen on one run of the m = 64 softmax golden, 0.8-0.97e-5 on others): 1.5e-5 for chains.
+MODULE_SCALE = {torch.float32: 1.5, torch.bfloat16: 5.0 / 3.0}
 DTYPES = [torch.float32, torch.bfloat16]
 IDS = ['f32', 'bf16']
 
