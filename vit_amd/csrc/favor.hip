@@ -380,8 +380,11 @@ __global__ __launch_bounds__(256) void favor_out_kernel(const FavorParams p) {
 //   d dd = e - [m = argmax] sum_m e (softmax kernel);  d diag = -sum_m e
 //   dQ[l] = d dd[l] . w + d diag * diag_c
 //   dKV^T[d][m] += dO^T[d][l] q'[l][m] / den[l];  dksum[m] += dden[l] q'[l][m]
+// launch bounds: two waves per SIMD.  Left alone the compiler took 200 VGPRs + 64 AGPRs -- eight over half the file, so ONE
+// workgroup per CU: 768 workgroups (ViT-S/16-384, batch 64) ran in three rounds of one wave per SIMD (725 -> 685 us for
+// the whole backward).  m = 256 keeps the whole file: at half of it that instance spills 1.4 KB per lane.
 template <typename T, int DKB, int MT>
-__global__ __launch_bounds__(256) void favor_bwd_q_kernel(const FavorParams p) {
+__global__ __launch_bounds__(256, MT <= 4 ? 2 : 1) void favor_bwd_q_kernel(const FavorParams p) {
     using C = ACfg<T, DKB>;
     constexpr int ASTR = C::ASTR;
     constexpr int ND = 2 * DKB;
