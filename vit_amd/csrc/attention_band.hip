@@ -2,21 +2,20 @@
 // configuration (197 tokens: one 13-tile chunk), of the CIFAR plumbing config (65) and, chunk by chunk, of 384 px
 // (577 tokens: three chunks).
 //
-// One workgroup (8 waves: two per SIMD, so one wave's LDS / MFMA latencies hide behind the other)
-// owns one (batch, head): the rows of the whole head are staged in LDS once per pass, and between
-// the few workgroup barriers the waves run independently -- no per-tile barriers, no
-// cross-workgroup reductions, no atomics, no fp32 workspace:
-//   forward : a wave owns query tiles qt = wave, wave+8, ...; lane = query (scores transposed),
-//             online softmax in registers, O^T += V^T P^T with P taken straight from the score
-//             accumulators.
-//   backward: pass 1 is KEY-stationary (a wave owns key tiles; dK^T, dV^T stay in registers while
-//             it sweeps the live query tiles) and leaves every 16 x 16 dS tile (bf16) in a
-//             workspace; pass 2 is QUERY-stationary (dQ^T in registers) and only reads those tiles
-//             back -- no second recompute of P -- as does the table-gradient kernel
-//             (attn_bwd_relds_kernel, attention_bwd.hip).  Pass 1 needs Q and dO in LDS (its own
-//             K / V rows come from global memory), pass 2 needs K: K is staged over Q between the
-//             passes, so the kernel holds TWO row images, not three, which is what lets 8 waves'
-//             scratch fit in the 160 KiB.  No dQ atomics, no fp32 dQ accumulator.
+// A workgroup owns one (batch, head, chunk of 13 tiles): the rows it needs are staged in LDS as whole chunk images, and
+// between the few workgroup barriers the waves run independently -- no per-tile barriers, no cross-workgroup
+// reductions, no atomics, no fp32 workspace:
+//   forward : 16 waves, wave < 13 owns query tile 13 chunk + wave; lane = query (scores transposed), online softmax
+//             in registers, O^T += V^T P^T with P taken straight from the score accumulators; the K / V images of the
+//             key chunks its band reaches are staged one after the other.
+//   backward: pass 1 is KEY-stationary (8 waves, a wave owns up to two key tiles; dK^T, dV^T stay in registers while
+//             it sweeps the live query tiles; Q and dO images in LDS, its own K / V rows from global memory) and leaves
+//             every 16 x 16 dS tile (bf16) in a workspace; pass 2 is QUERY-stationary (dQ^T in registers, K image in
+//             LDS) and only reads those tiles back -- no second recompute of P -- as does the table-gradient kernel
+//             (attn_bwd_relds_kernel, attention_bwd.hip).  A head of ONE chunk (every 224-px configuration) runs both
+//             passes in one kernel, K staged over Q in between (two row images, not three: what lets 8 waves'
+//             scratch fit in the 160 KiB); longer heads run them as two kernels over (head, chunk) grids.
+//             No dQ atomics, no fp32 dQ accumulator.
 // The LAI band (|i-j| <= w) limits a tile row / column to 2*cmax+1 live tile diagonals,
 // cmax = (w+15)/16 (NT-1 when unmasked).  With the disentangled bias the live diagonals are walked
 // in GROUPS of up to 5 (c_lo .. c_lo+4): the 96 relative-table rows a group can touch are staged,
