@@ -236,11 +236,16 @@ def main():
     kernels = None
     if timer:
         agg = {}
+        spans = []                 # (start, end) of every GEMM launch on the first event's clock, for the union below
+        base = timer[0][2]
         for name, work, e0, e1, unit in timer:
             a = agg.setdefault(name, [0.0, 0.0, 0, unit])
             a[0] += work
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+            if unit == 'flop':
+                t0 = base.elapsed_time(e0) * 1e-3
+                spans.append((t0, t0 + e0.elapsed_time(e1) * 1e-3))
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
 
         def line(name):
@@ -283,8 +288,23 @@ def main():
         roofline['traffic_unit'] = 'bytes/launch (PMC)'
         roofline['traffic_source'] = note
         if gemms:
-            roofline['all_gemm_tflops'] = sum(agg[k][0] for k in gemms) / sum(agg[k][1] for k in gemms) / 1e12
-            roofline['all_gemm_share_of_step_time'] = sum(agg[k][1] for k in gemms) / elapsed
+            # the weight-gradient GEMMs run on a second stream and overlap the others (functional._dw): summed per-launch
+            # durations would count the shared time twice, so the aggregate is taken over the UNION of the launches' spans
+            spans.sort()
+            busy, cur0, cur1 = 0.0, None, None
+            for t0, t1 in spans:
+                if cur1 is None or t0 > cur1:
+                    if cur1 is not None:
+                        busy += cur1 - cur0
+                    cur0, cur1 = t0, t1
+                else:
+                    cur1 = max(cur1, t1)
+            if cur1 is not None:
+                busy += cur1 - cur0
+            roofline['all_gemm_tflops'] = sum(agg[k][0] for k in gemms) / busy / 1e12
+            roofline['all_gemm_share_of_step_time'] = busy / elapsed
+            roofline['overlap_note'] = ('dW GEMMs (gemm_TN) run on a second stream beside the dX GEMMs: per-launch durations include '
+                                        'the time they share CUs; all_gemm_* are over the union of the launch spans')
         kernels = [line(k) for k in sorted(agg, key=lambda k: -agg[k][1])]
 
     if rank == 0:
