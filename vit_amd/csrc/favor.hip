@@ -22,131 +22,9 @@
 // operand of the next product (sum over m).  Products that sum over l (KV, dKV) recompute dd with
 // l in the accumulator ROWS and take V / dO through a wave-private LDS image (hardware transposed
 // read for bf16).
-#include "attn_common.h"
+#include "favor_common.h"
 
 namespace vitk {
-
-enum { FAVOR_SOFTMAX = 0, FAVOR_RELU = 1 };
-
-struct FavorParams {
-    const void *q, *k, *v;
-    long ld;
-    const void* w;          // [m][dh], T
-    void* kvt;              // [B][H][dh][mp]  T   (KV transposed: rows d)
-    void* kv;               // [B][H][mp][dhp] T   (KV: rows m)
-    float* ksum;            // [B][H][mp]
-    unsigned long long* kmax;   // packed (ordered float bits << 32 | flat index)
-    void* out;
-    long ldo;
-    const void* dout;
-    float* dkvt;            // [B][H][dh][mp]  fp32 (backward: d KV transposed)
-    float* dksum;           // [B][H][mp]
-    void *dkvt_t, *dkv_t;   // T copies of dKV in both layouts (written by the q-side backward)
-    float *kv32, *dkv32;    // fp32 [B][H][mp][dhp] copies: the two cancelling products of the backward use them
-    float* esum;            // partial sums of the key-side exp gradients: [nesum] (one per (b, h); per (l, h) for the
-                            // position tables), added up by favor_fix -- one shared address would serialise ~25k atomics
-    int nesum;
-    void *dq, *dk, *dv;
-    long ld_d;
-    // position features (DisentangledSelfAttentionPerformer): q' += pq[l][h][.], k' += pk[l][h][.]  (fp32 [L][H][mp],
-    // the same for every b); the backward leaves d(q' + pq) / d(k' + pk) per b in dnq / dnk (fp32 [B][L][H][mp])
-    const float *pq, *pk;
-    float *dnq, *dnk;
-    int B, H, L, dh, m, mp, dhp;
-    int kv_groups;          // 64-token groups per workgroup of the staged key-side backward
-    int kind;
-    float ratio, eps, diag_c;
-};
-
-__device__ __forceinline__ unsigned int ordered_bits(float f) {
-    const unsigned int u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float unordered_bits(unsigned int k) {
-    const unsigned int u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-
-template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
-template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-template <> __device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
-    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
-    return f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
-}
-template <typename T> __device__ __forceinline__ void store4(T* p, const f32x4& v);
-template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, const f32x4& v) {
-    *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-}
-
-// Fragment whose 8 k-slots are two runs of 4 consecutive elements (p0[0..3], p1[0..3]): the k order
-// of acc_to_frag (tile a rows 4g..4g+3, tile b rows 4g..4g+3).
-template <typename T> __device__ __forceinline__ void frag_load_split(Frag<T>& f, const T* p0, const T* p1, bool ok1) {
-    const f32x4 a = load4<T>(p0);
-    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-    if (ok1) b = load4<T>(p1);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        frag_set_f(f, e, a[e]);
-        frag_set_f(f, 4 + e, b[e]);
-    }
-}
-
-// bf16 hi / lo split of fp32 values: x ~ hi + lo to ~16 mantissa bits.  The backward's two
-// cancelling products (KV . dnum + dden ksum, dKV . v + dksum) run as hi.hi + hi.lo + lo.hi so the
-// bf16 path keeps fp32-like accuracy exactly where rounding would be amplified.
-__device__ __forceinline__ void split_set(Frag<__bf16>& hi, Frag<__bf16>& lo, int e, float x) {
-    const __bf16 h = (__bf16)x;
-    hi.v[e] = h;
-    lo.v[e] = (__bf16)(x - (float)h);
-}
-__device__ __forceinline__ void acc_to_frag_hilo(Frag<__bf16>& hi, Frag<__bf16>& lo, const f32x4& a, const f32x4& b) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        split_set(hi, lo, e, a[e]);
-        split_set(hi, lo, 4 + e, b[e]);
-    }
-}
-
-// feature value and its derivative factor d val / d dd (without the max-routing term)
-__device__ __forceinline__ float feat(int kind, float dd, float diag, float stab, float ratio, float eps) {
-    if (kind == FAVOR_SOFTMAX) return ratio * (expf(dd - diag - stab) + eps);
-    return fmaxf(ratio * dd, 0.f) + eps;
-}
-__device__ __forceinline__ float feat_grad(int kind, float dd, float diag, float stab, float ratio) {
-    if (kind == FAVOR_SOFTMAX) return ratio * expf(dd - diag - stab);
-    return dd > 0.f ? ratio : 0.f;
-}
-
-// dd^T tiles for the 16 tokens of a fragment set: acc[mt][r] = dd[token li][feature 16mt + 4g + r]
-template <typename T, int DKB, int MT>
-__device__ __forceinline__ void ddT_tiles(f32x4 (&acc)[MT], const Frag<T> (&xf)[DKB], const T* __restrict__ w, int m,
-                                          int dh, int lane) {
-    const int g = lane >> 4, li = lane & 15;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < DKB; ++kb) {
-            Frag<T> wf;
-            row_frag_global<T>(wf, w, dh, 16 * mt + li, m, dh, kb, lane);
-            s = mma(wf, xf[kb], s);
-        }
-        acc[mt] = s;
-    }
-}
-
-// per-token sum of the data row (lane = token): sum of the lane's fragment elements over g
-template <typename T, int DKB> __device__ __forceinline__ float row_sum(const Frag<T> (&xf)[DKB]) {
-    float s = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < DKB; ++kb)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += frag_get_f(xf[kb], e);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    return s;
-}
 
 // ------------------------------------------------------------------ global key max (+ argmax)
 template <typename T, int DKB, int MT>
@@ -721,206 +599,6 @@ __global__ __launch_bounds__(256) void favor_bwd_kv_kernel(const FavorParams p) 
     }
 }
 
-// The same, for m <= 64 (MT <= 4), with everything that is per (b, h) rather than per token staged in LDS once per
-// workgroup -- w row-major and transposed, dKV (bf16: as hi / lo images), dKV^T, dksum -- and a loop over p.kv_groups
-// 64-token groups: the plain kernel re-reads those ~50 fragments per wave from L2 (a third of its time was waiting
-// for them) and transposes w with 2-byte strided loads in every workgroup's prologue.  The next group's K / V rows
-// are fetched while the current one is in the MFMAs.
-template <typename T, int DKB, int MT> struct FavorKvStage {
-    static constexpr int MP = 16 * MT;
-    static constexpr int DHP = 32 * DKB;
-    static constexpr int WLD = DHP + 16 / sizeof(T);          // row-major images: [MP][WLD]
-    static constexpr int WTLD = MP + 8;                       // transposed images: [DHP][WTLD]
-    static constexpr int DLD = DHP + 8;                       // bf16 hi / lo images of dKV
-    static constexpr size_t dkv_bytes = sizeof(T) == 2 ? (size_t)2 * MP * DLD * 2 : (size_t)MP * WLD * 4;
-    static constexpr size_t bytes = (size_t)(MP * WLD + 2 * DHP * WTLD) * sizeof(T) + dkv_bytes + (size_t)MP * 4;
-};
-
-template <typename T, int DKB, int MT>
-__global__ __launch_bounds__(256) void favor_bwd_kv_staged_kernel(const FavorParams p) {
-    using S = FavorKvStage<T, DKB, MT>;
-    constexpr int ND = 2 * DKB;
-    constexpr int MP = S::MP, DHP = S::DHP, WLD = S::WLD, WTLD = S::WTLD, DLD = S::DLD;
-    constexpr int EPC = 16 / sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int L = p.L, dh = p.dh, m = p.m;
-    T* wr = reinterpret_cast<T*>(smem);                       // w, rows m
-    T* wT = wr + MP * WLD;                                    // w^T, rows d
-    T* dkvT = wT + DHP * WTLD;                                // dKV^T, rows d
-    char* dimg = reinterpret_cast<char*>(dkvT + DHP * WTLD);  // dKV, rows m
-    float* dks = reinterpret_cast<float*>(dimg + S::dkv_bytes);
-    const T* W = reinterpret_cast<const T*>(p.w);
-    const long bh = (long)b * p.H + h;
-    const T* DKVT = reinterpret_cast<const T*>(p.dkvt_t) + bh * dh * p.mp;
-    const float* DKV32 = p.dkv32 + bh * p.mp * p.dhp;
-    for (int c = tid; c < MP * (DHP / EPC); c += 256) {       // w: 16-byte chunks in, rows and columns out
-        const int mm = c / (DHP / EPC), d0 = (c - mm * (DHP / EPC)) * EPC;
-        u32x4 raw = {0, 0, 0, 0};
-        if (mm < m && d0 < dh) raw = *reinterpret_cast<const u32x4*>(W + (long)mm * dh + d0);
-        *reinterpret_cast<u32x4*>(wr + mm * WLD + d0) = raw;
-        const T* e = reinterpret_cast<const T*>(&raw);
-#pragma unroll
-        for (int j = 0; j < EPC; ++j) wT[(d0 + j) * WTLD + mm] = e[j];
-    }
-    for (int c = tid; c < DHP * (MP / EPC); c += 256) {       // dKV^T (rows d >= dh do not exist: zeros)
-        const int d = c / (MP / EPC), m0 = (c - d * (MP / EPC)) * EPC;
-        u32x4 raw = {0, 0, 0, 0};
-        if (d < dh) raw = *reinterpret_cast<const u32x4*>(DKVT + (long)d * p.mp + m0);
-        *reinterpret_cast<u32x4*>(dkvT + d * WTLD + m0) = raw;
-    }
-    for (int c = tid; c < MP * (DHP / 4); c += 256) {         // dKV from its fp32 copy
-        const int mm = c / (DHP / 4), d0 = (c - mm * (DHP / 4)) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(DKV32 + (long)mm * p.dhp + d0);
-        if constexpr (sizeof(T) == 2) {
-            __bf16* hi = reinterpret_cast<__bf16*>(dimg) + mm * DLD + d0;
-            __bf16* lo = hi + MP * DLD;
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                vh[j] = (__bf16)v[j];
-                vl[j] = (__bf16)(v[j] - (float)vh[j]);
-            }
-            *reinterpret_cast<bf16x4*>(hi) = vh;
-            *reinterpret_cast<bf16x4*>(lo) = vl;
-        } else {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dimg) + mm * WLD + d0) = v;
-        }
-    }
-    for (int i = tid; i < MP; i += 256) dks[i] = p.dksum[bh * p.mp + i];
-    __syncthreads();
-
-    const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
-    const T* V = reinterpret_cast<const T*>(p.v) + (long)b * L * p.ld + h * dh;
-    float stab = 0.f;
-    if (p.kind == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(*p.kmax >> 32));
-    const int ngroups = (L + 63) / 64;
-    const int g0 = blockIdx.x * p.kv_groups;
-    const int g1 = min(g0 + p.kv_groups, ngroups);
-    Frag<T> xf[DKB], vf[DKB];
-#pragma unroll
-    for (int kb = 0; kb < DKB; ++kb) {
-        row_frag_global<T>(xf[kb], K, p.ld, g0 * 64 + 16 * wave + li, L, dh, kb, lane);
-        row_frag_global<T>(vf[kb], V, p.ld, g0 * 64 + 16 * wave + li, L, dh, kb, lane);
-    }
-    float esum_w = 0.f;
-    for (int grp = g0; grp < g1; ++grp) {
-        const int l0 = grp * 64 + 16 * wave;
-        const int l = l0 + li;
-        Frag<T> xn[DKB], vn[DKB];
-#pragma unroll
-        for (int kb = 0; kb < DKB; ++kb) {
-            const int ln = grp + 1 < g1 ? l + 64 : L;         // past the end: zero fragments, no load
-            row_frag_global<T>(xn[kb], K, p.ld, ln, L, dh, kb, lane);
-            row_frag_global<T>(vn[kb], V, p.ld, ln, L, dh, kb, lane);
-        }
-        if (l0 < L) {
-            const float diag = row_sum<T, DKB>(xf) * p.diag_c;
-            f32x4 kp[MT], e[MT];
-            float esum = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x4 dd = {0.f, 0.f, 0.f, 0.f}, s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < DKB; ++kb) {
-                    Frag<T> wf;
-                    frag_load(wf, wr + (16 * mt + li) * WLD + 32 * kb + 8 * g);
-                    dd = mma(wf, xf[kb], dd);                                        // dd^T[m][l]
-                    if constexpr (sizeof(T) == 2) {
-                        const __bf16* hi = reinterpret_cast<const __bf16*>(dimg) + (16 * mt + li) * DLD + 32 * kb + 8 * g;
-                        Frag<__bf16> ah, alo;
-                        frag_load(ah, hi);
-                        frag_load(alo, hi + MP * DLD);
-                        s = mma(ah, vf[kb], s);
-                        s = mma(alo, vf[kb], s);
-                    } else {
-                        Frag<T> a;
-                        frag_load(a, reinterpret_cast<const float*>(dimg) + (16 * mt + li) * WLD + 32 * kb + 8 * g);
-                        s = mma(a, vf[kb], s);                                       // dk'^T[m][l]
-                    }
-                }
-                const f32x4 dksv = *reinterpret_cast<const f32x4*>(dks + 16 * mt + 4 * g);
-                f32x4 pkv = {0.f, 0.f, 0.f, 0.f}, dnew;
-                if (p.pk && l < L) pkv = *reinterpret_cast<const f32x4*>(p.pk + ((long)l * p.H + h) * p.mp + 16 * mt + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (16 * mt + 4 * g + r < m) && (l < L);
-                    kp[mt][r] = ok ? feat(p.kind, dd[r], diag, stab, p.ratio, p.eps) + pkv[r] : 0.f;
-                    dnew[r] = ok ? s[r] + dksv[r] : 0.f;
-                    e[mt][r] = ok ? dnew[r] * feat_grad(p.kind, dd[r], diag, stab, p.ratio) : 0.f;
-                    esum += e[mt][r];
-                }
-                if (p.dnk && l < L)
-                    *reinterpret_cast<f32x4*>(p.dnk + (((long)b * L + l) * p.H + h) * p.mp + 16 * mt + 4 * g) = dnew;
-            }
-            esum_w += esum;
-            float esum_l = esum;
-            esum_l += __shfl_xor(esum_l, 16, 64);
-            esum_l += __shfl_xor(esum_l, 32, 64);
-            const float ddiag = p.kind == FAVOR_SOFTMAX ? -esum_l * p.diag_c : 0.f;
-            T* DK = reinterpret_cast<T*>(p.dk) + ((long)b * L + l) * p.ld_d + h * dh;
-            T* DV = reinterpret_cast<T*>(p.dv) + ((long)b * L + l) * p.ld_d + h * dh;
-            Frag<T> be[(MT + 1) / 2], bk[(MT + 1) / 2];
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mb = 0; mb < (MT + 1) / 2; ++mb) {
-                const bool has2 = 2 * mb + 1 < MT;
-                acc_to_frag(be[mb], e[2 * mb], has2 ? e[2 * mb + 1] : zero);
-                acc_to_frag(bk[mb], kp[2 * mb], has2 ? kp[2 * mb + 1] : zero);
-            }
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt) {
-                f32x4 sk = {ddiag, ddiag, ddiag, ddiag}, sv = {0.f, 0.f, 0.f, 0.f};
-                const T* wrow = wT + (16 * dt + li) * WTLD;
-                const T* drow = dkvT + (16 * dt + li) * WTLD;
-#pragma unroll
-                for (int mb = 0; mb < (MT + 1) / 2; ++mb) {
-                    const bool has2 = 2 * mb + 1 < MT;
-                    Frag<T> a, a2;
-                    frag_load_split<T>(a, wrow + 32 * mb + 4 * g, wrow + 32 * mb + 16 + 4 * g, has2);
-                    frag_load_split<T>(a2, drow + 32 * mb + 4 * g, drow + 32 * mb + 16 + 4 * g, has2);
-                    sk = mma(a, be[mb], sk);
-                    sv = mma(a2, bk[mb], sv);
-                }
-                const int d0 = 16 * dt + 4 * g;
-                if (l < L && d0 < dh) {
-                    store4<T>(DK + d0, sk);
-                    store4<T>(DV + d0, sv);
-                }
-            }
-        }
-#pragma unroll
-        for (int kb = 0; kb < DKB; ++kb) {
-            xf[kb] = xn[kb];
-            vf[kb] = vn[kb];
-        }
-    }
-    if (p.kind == FAVOR_SOFTMAX) {
-        const float tot = wave_sum(esum_w);
-        if (lane == 0) atomicAdd(p.esum + bh, tot);
-    }
-}
-
-// the global-max element of the key features receives minus the whole tensor's exp-gradient sum
-template <typename T>
-__global__ void favor_fix_kernel(const FavorParams p) {
-    const unsigned long long key = *p.kmax;
-    const unsigned long long idx = 0xffffffffull - (key & 0xffffffffull);
-    const int mi = idx % p.m;
-    const unsigned long long t = idx / p.m;
-    const int h = t % p.H;
-    const long bl = t / p.H;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < p.nesum; i += 64) s += p.esum[i];      // launched with one wave
-    s = wave_sum(s);
-    const T* W = reinterpret_cast<const T*>(p.w);
-    T* DK = reinterpret_cast<T*>(p.dk) + bl * p.ld_d + h * p.dh;
-    for (int d = threadIdx.x; d < p.dh; d += blockDim.x)
-        DK[d] = from_f32<T>(to_f32<T>(DK[d]) - s * to_f32<T>(W[(long)mi * p.dh + d]));
-}
-
 // ------------------------------------------------------------------ position feature tables
 // The feature map on its own, applied to the [L, H*dh] projections of pos_embed (one "batch"):
 // P[l][h][.] fp32 with pitch mp (DisentangledSelfAttentionPerformer.disentangled_attention_perf_bias,
@@ -1120,23 +798,7 @@ template <typename T, int DKB, int MT> void launch_bwd(const FavorParams& p, hip
         attr = true;
     }
     hipLaunchKernelGGL((favor_bwd_q_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), lds_q, st, p);
-    if constexpr (MT <= 4) {
-        // one workgroup stages the (b, h) state once and walks kv_groups 64-token groups: as many as leaves ~3
-        // workgroups per CU in flight
-        constexpr size_t lds_s = FavorKvStage<T, DKB, MT>::bytes;
-        static bool attr_s = false;
-        if (!attr_s) {
-            (void)hipFuncSetAttribute((const void*)favor_bwd_kv_staged_kernel<T, DKB, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            attr_s = true;
-        }
-        const int ng = (p.L + 63) / 64;
-        FavorParams ps = p;
-        ps.kv_groups = (int)std::max(1L, std::min((long)ng, (long)p.B * p.H * ng / 768));
-        hipLaunchKernelGGL((favor_bwd_kv_staged_kernel<T, DKB, MT>), dim3((ng + ps.kv_groups - 1) / ps.kv_groups, p.H, p.B),
-                           dim3(256), lds_s, st, ps);
-    } else {
-        hipLaunchKernelGGL((favor_bwd_kv_kernel<T, DKB, MT>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), lds_k, st, p);
-    }
+    hipLaunchKernelGGL((favor_bwd_kv_kernel<T, DKB, MT>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), lds_k, st, p);
     if (p.kind == FAVOR_SOFTMAX) hipLaunchKernelGGL(favor_fix_kernel<T>, dim3(1), dim3(64), 0, st, p);
 }
 
@@ -1148,12 +810,12 @@ template <typename T, int DKB> void dispatch_mt(const FavorParams& p, bool bwd, 
         else launch_fwd<T, DKB, M>(p, st);          \
     } while (0)
     if (mt == 1) VITK_FV(1);
-    else if (mt == 4) VITK_FV(4);
-    else VITK_FV(16);
+    else VITK_FV(16);          // mt == 4 never gets here (favor_fast.hip)
 #undef VITK_FV
 }
 
 void dispatch(const FavorParams& p, int dtype, bool bwd, hipStream_t st) {
+    if (favor_fast_launch(p, dtype, bwd, st)) return;          // 17..64 features: favor_fast.hip
     const int dkb = (p.dh + 31) / 32;
     if (dtype == VITK_BF16) {
         if (dkb == 1) dispatch_mt<__bf16, 1>(p, bwd, st);
