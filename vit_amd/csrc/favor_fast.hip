@@ -25,7 +25,7 @@ template <typename T, int DKB, int MT> struct FastCfg {
     static constexpr int RLD = MP + 4;                        // fp32 reduction image [DHP][RLD]
     static constexpr size_t hilo_bytes = sizeof(T) == 2 ? (size_t)2 * MP * DLD * 2 : (size_t)MP * WLD * 4;
     static constexpr size_t out_bytes = (size_t)(MP * WLD + DHP * WTLD) * sizeof(T) + (size_t)MP * 4;
-    static constexpr size_t kv_bytes = (size_t)4 * 32 * C::ASTR * sizeof(T) + (size_t)(DHP * RLD + MP) * 4;
+    static constexpr size_t kv_bytes(int mtc) { return (size_t)4 * 32 * C::ASTR * sizeof(T) + (size_t)(DHP * (16 * mtc + 4) + 16 * mtc) * 4; }
     static constexpr size_t bwd_q_bytes = (size_t)(MP * WLD + DHP * WTLD + 4 * 16 * C::ASTR) * sizeof(T) + hilo_bytes +
                                           (size_t)(DHP * RLD + 2 * MP + 4 * 64) * 4;
     static constexpr size_t bwd_kv_bytes = (size_t)(MP * WLD + 2 * DHP * WTLD) * sizeof(T) + hilo_bytes + (size_t)MP * 4;
@@ -142,23 +142,26 @@ __global__ __launch_bounds__(256) void favor_kmax_fast_kernel(const FavorParams 
 }
 
 // ------------------------------------------------------------------ KV, ksum
-// grid (H, B); as favor_kv_kernel with all MT feature tiles in one workgroup and the next 32 K / V rows in flight.
-template <typename T, int DKB, int MT, int KIND, bool POS>
-__global__ __launch_bounds__(256) void favor_kv_fast_kernel(const FavorParams p) {
+// grid (H, B, MT / MTC); as favor_kv_kernel, with the next 32 K / V rows in flight.  A workgroup owns MTC of the MT
+// feature tiles (its own columns of KV: no exchange, the same sums in the same order whatever MTC is): with all four
+// the accumulators take half the register file, two workgroups fit a CU and 768 of them run in a round and a half;
+// with two, 1536 half-sized workgroups run three to a CU in two full rounds.
+template <typename T, int DKB, int MT, int MTC, int KIND, bool POS>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? (MTC <= 2 ? 3 : 2) : 1) void favor_kv_fast_kernel(const FavorParams p) {
     using F = FastCfg<T, DKB, MT>;
     using C = ACfg<T, DKB>;
-    constexpr int ASTR = C::ASTR, ND = 2 * DKB, RLD = F::RLD, MP = F::MP, DHP = F::DHP, EPC = F::EPC;
+    constexpr int ASTR = C::ASTR, ND = 2 * DKB, MPC = 16 * MTC, RLD = MPC + 4, DHP = F::DHP, EPC = F::EPC;
     constexpr int NV = 32 * C::CPR / 64;                      // 16-byte chunks of the 32-row V image per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.x, b = blockIdx.y;
+    const int h = blockIdx.x, b = blockIdx.y, mc0 = blockIdx.z * MPC;
     const int L = p.L, dh = p.dh, m = p.m;
     const long bh = (long)b * p.H + h;
     T* Vw = reinterpret_cast<T*>(smem) + wave * 32 * ASTR;
-    float* red = reinterpret_cast<float*>(reinterpret_cast<T*>(smem) + 4 * 32 * ASTR);   // [DHP][RLD] + ksum[MP]
+    float* red = reinterpret_cast<float*>(reinterpret_cast<T*>(smem) + 4 * 32 * ASTR);   // [DHP][RLD] + ksum[MPC]
     float* ksr = red + DHP * RLD;
-    for (int i = tid; i < DHP * RLD + MP; i += 256) red[i] = 0.f;
+    for (int i = tid; i < DHP * RLD + MPC; i += 256) red[i] = 0.f;
     __syncthreads();
 
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
@@ -170,16 +173,15 @@ __global__ __launch_bounds__(256) void favor_kv_fast_kernel(const FavorParams p)
     Frag<T> ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) frag_set_f(ones, e, 1.f);
-    Frag<T> wf[MT][DKB];
+    Frag<T> wf[MTC][DKB];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTC; ++mt)
 #pragma unroll
-        for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(wf[mt][kb], W, dh, 16 * mt + li, m, dh, kb, lane);
-
-    f32x4 acc[ND][MT];
-    float ks[MT];
+        for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(wf[mt][kb], W, dh, mc0 + 16 * mt + li, m, dh, kb, lane);
+    f32x4 acc[ND][MTC];
+    float ks[MTC];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MTC; ++mt) {
         ks[mt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) acc[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -208,23 +210,23 @@ __global__ __launch_bounds__(256) void favor_kv_fast_kernel(const FavorParams p)
         Frag<T> xn[2][DKB];
         u32x4 vrawn[NV];
         fetch(l0 + 128 < L ? l0 + 128 : L, xn, vrawn);        // past the end: zeros, no loads
-        f32x4 kp[2][MT];
+        f32x4 kp[2][MTC];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             f32x4 dg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < DKB; ++kb) dg = mma(xf[u][kb], ones, dg);      // row sums of K: dg[r] = sum_d K[4g+r][d]
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MTC; ++mt) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < DKB; ++kb) s = mma(xf[u][kb], wf[mt][kb], s);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int lt = l0 + 16 * u + 4 * g + r;
-                    const bool ok = (lt < L) && (16 * mt + li < m);
-                    float v = feat_t<KIND>(s[r], feat_exp<KIND>(s[r], dg[r] * p.diag_c, stab), p.ratio, p.eps);
-                    if constexpr (POS) v += p.pk[((long)min(lt, L - 1) * p.H + h) * p.mp + 16 * mt + li];
+                    const bool ok = (lt < L) && (mc0 + 16 * mt + li < m);
+                    float v = feat_t<KIND>(s[r], feat_exp<KIND, T>(s[r], dg[r] * p.diag_c, stab), p.ratio, p.eps);
+                    if constexpr (POS) v += p.pk[((long)min(lt, L - 1) * p.H + h) * p.mp + mc0 + 16 * mt + li];
                     v = ok ? v : 0.f;
                     kp[u][mt][r] = v;
                     ks[mt] += v;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void favor_kv_fast_kernel(const FavorParams p)
         }
         wave_lds_sync();
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MTC; ++mt) {
             Frag<T> bf;
             acc_to_frag(bf, kp[0][mt], kp[1][mt]);
 #pragma unroll
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void favor_kv_fast_kernel(const FavorParams p)
     for (int wv = 0; wv < 4; ++wv) {
         if (wave == wv) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MTC; ++mt) {
                 float s = ks[mt];
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
@@ -268,14 +270,14 @@ __global__ __launch_bounds__(256) void favor_kv_fast_kernel(const FavorParams p)
     }
     T* KVT = reinterpret_cast<T*>(p.kvt) + bh * dh * p.mp;
     T* KV = reinterpret_cast<T*>(p.kv) + bh * p.mp * p.dhp;
-    for (int i = tid; i < DHP * MP; i += 256) {
-        const int d = i / MP, mm = i - d * MP;
+    for (int i = tid; i < DHP * MPC; i += 256) {
+        const int d = i / MPC, mm = i - d * MPC;
         const float v = d < dh ? red[d * RLD + mm] : 0.f;
-        if (d < dh) KVT[(long)d * p.mp + mm] = from_f32<T>(v);
-        KV[(long)mm * p.dhp + d] = from_f32<T>(v);
-        p.kv32[(bh * p.mp + mm) * p.dhp + d] = v;
+        if (d < dh) KVT[(long)d * p.mp + mc0 + mm] = from_f32<T>(v);
+        KV[(long)(mc0 + mm) * p.dhp + d] = from_f32<T>(v);
+        p.kv32[(bh * p.mp + mc0 + mm) * p.dhp + d] = v;
     }
-    for (int i = tid; i < MP; i += 256) p.ksum[bh * p.mp + i] = ksr[i];
+    for (int i = tid; i < MPC; i += 256) p.ksum[bh * p.mp + mc0 + i] = ksr[i];
 }
 
 // ------------------------------------------------------------------ out = (q' KV) / (q' . ksum)
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void favor_out_fast_kernel(const FavorParams p
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = 16 * mt + 4 * g + r < m;
-                    const float f = feat_t<KIND>(dd[mt][r], feat_exp<KIND>(dd[mt][r], diag, mx), p.ratio, p.eps) + pqv[r];
+                    const float f = feat_t<KIND>(dd[mt][r], feat_exp<KIND, T>(dd[mt][r], diag, mx), p.ratio, p.eps) + pqv[r];
                     const float v = ok ? f : 0.f;
                     dd[mt][r] = v;
                     den += v * ksv[r];
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256) void favor_out_fast_kernel(const FavorParams p
 // ------------------------------------------------------------------ backward, query side
 // One workgroup per (b, h); waves split the tokens in blocks of 16 (see favor_bwd_q_kernel for the algebra).
 template <typename T, int DKB, int MT, int KIND, bool POS>
-__global__ __launch_bounds__(256, 2) void favor_bwd_q_fast_kernel(const FavorParams p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_kernel(const FavorParams p) {
     using F = FastCfg<T, DKB, MT>;
     using C = ACfg<T, DKB>;
     constexpr int ASTR = C::ASTR, ND = 2 * DKB;
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void favor_bwd_q_fast_kernel(const FavorPar
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = 16 * mt + 4 * g + r < m;
-                ex[mt][r] = feat_exp<KIND>(dd[mt][r], diag, mx);
+                ex[mt][r] = feat_exp<KIND, T>(dd[mt][r], diag, mx);
                 const float f = feat_t<KIND>(dd[mt][r], ex[mt][r], p.ratio, p.eps) + pqv[r];
                 den += ok ? f * ksv[r] : 0.f;
             }
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void favor_bwd_q_fast_kernel(const FavorPar
             for (int r = 0; r < 4; ++r) {
                 const int lr = 4 * g + r;
                 const bool ok = (l0 + lr < L) && (16 * mt + li < m);
-                float v = feat_t<KIND>(s[r], feat_exp<KIND>(s[r], r_diag[r], r_mx[r]), p.ratio, p.eps);
+                float v = feat_t<KIND>(s[r], feat_exp<KIND, T>(s[r], r_diag[r], r_mx[r]), p.ratio, p.eps);
                 if constexpr (POS) v += p.pq[((long)min(l0 + lr, L - 1) * p.H + h) * p.mp + 16 * mt + li];
                 v = ok ? v : 0.f;
                 dks[mt] += v * r_dden[r];
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256) void favor_bwd_kv_fast_kernel(const FavorParam
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = (16 * mt + 4 * g + r < m) && (l < L);
-                    const float ex = feat_exp<KIND>(dd[r], diag, stab);
+                    const float ex = feat_exp<KIND, T>(dd[r], diag, stab);
                     const float f = feat_t<KIND>(dd[r], ex, p.ratio, p.eps) + pkv[r];
                     kp[mt][r] = ok ? f : 0.f;
                     dnew[r] = ok ? s[r] + dksv[r] : 0.f;
@@ -792,13 +794,13 @@ int pick_groups(const FavorParams& p, long want) {
 }
 
 template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorParams& p0, bool bwd, hipStream_t st) {
-    constexpr int MT = 4;
+    constexpr int MT = 4, MTC = 2;        // MTC: feature tiles per workgroup of the KV kernel
     using F = FastCfg<T, DKB, MT>;
     FavorParams p = p0;
     const int ng = (p.L + 63) / 64;
     static bool attr = false;
     if (!attr) {
-        set_lds(favor_kv_fast_kernel<T, DKB, MT, KIND, POS>, F::kv_bytes);
+        set_lds(favor_kv_fast_kernel<T, DKB, MT, MTC, KIND, POS>, F::kv_bytes(MTC));
         set_lds(favor_out_fast_kernel<T, DKB, MT, KIND, POS>, F::out_bytes);
         set_lds(favor_bwd_q_fast_kernel<T, DKB, MT, KIND, POS>, F::bwd_q_bytes);
         set_lds(favor_bwd_kv_fast_kernel<T, DKB, MT, KIND, POS>, F::bwd_kv_bytes);
@@ -809,7 +811,7 @@ template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorP
             (void)vitk_zero_async(p.kmax, 8, 8, 1, st);
             hipLaunchKernelGGL((favor_kmax_fast_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), 0, st, p);
         }
-        hipLaunchKernelGGL((favor_kv_fast_kernel<T, DKB, MT, KIND, POS>), dim3(p.H, p.B), dim3(256), F::kv_bytes, st, p);
+        hipLaunchKernelGGL((favor_kv_fast_kernel<T, DKB, MT, MTC, KIND, POS>), dim3(p.H, p.B, MT / MTC), dim3(256), F::kv_bytes(MTC), st, p);
         p.groups = pick_groups(p, 1536);
         hipLaunchKernelGGL((favor_out_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
                            dim3(256), F::out_bytes, st, p);
