@@ -850,6 +850,7 @@ static int favor_setup(FavorParams& p, int dtype, int kind, int B, int H, int L,
     auto al = [](long x) { return (x + 255) / 256 * 256; };
     char* ws = reinterpret_cast<char*>(workspace);
     p.kmax = reinterpret_cast<unsigned long long*>(ws);
+    p.kmax_slots = 1;
     ws += 256;
     p.ksum = reinterpret_cast<float*>(ws); ws += al(bh * mp * 4);
     p.dksum = reinterpret_cast<float*>(ws); ws += al(bh * mp * 4);
@@ -979,6 +980,7 @@ static void favor_pos_params(FavorParams& p, int kind, int H, int L, int dh, int
                              float ratio, float eps, void* state) {
     p.q = x; p.ld = ld; p.w = w;
     p.kmax = reinterpret_cast<unsigned long long*>(state);
+    p.kmax_slots = 1;
     p.esum = reinterpret_cast<float*>(reinterpret_cast<char*>(state) + 64);
     p.nesum = L * H;
     p.B = 1; p.H = H; p.L = L; p.dh = dh; p.m = m; p.mp = 16 * pick_mt(m);

@@ -14,7 +14,8 @@ struct FavorParams {
     void* kvt;              // [B][H][dh][mp]  T   (KV transposed: rows d)
     void* kv;               // [B][H][mp][dhp] T   (KV: rows m)
     float* ksum;            // [B][H][mp]
-    unsigned long long* kmax;   // packed (ordered float bits << 32 | flat index)
+    unsigned long long* kmax;   // packed (ordered float bits << 32 | flat index); kmax_slots cells, the maximum is over all
+    int kmax_slots;             // 1 (favor.hip) or KMAX_SLOTS (favor_fast.hip: one cell took ~10 ns per visiting wave)
     void* out;
     long ldo;
     const void* dout;
@@ -145,10 +146,25 @@ template <int KIND> __device__ __forceinline__ float feat_grad_t(float dd, float
     else return dd > 0.f ? ratio : 0.f;
 }
 
+// The key maximum is kept in up to KMAX_SLOTS cells (the first 256 bytes of the workspace), each the maximum of the
+// workgroups that hash to it: every reader takes the maximum over the cells.  All lanes of the wave get the result.
+constexpr int KMAX_SLOTS = 32;
+__device__ __forceinline__ unsigned long long kmax_all(const unsigned long long* kmax, int nslots, int lane) {
+    unsigned long long v = lane < nslots ? kmax[lane] : 0ull;
+    if (nslots > 1) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(v, o, 64);
+            v = other > v ? other : v;
+        }
+    }
+    return __shfl(v, 0, 64);
+}
+
 // the global-max element of the key features receives minus the whole tensor's exp-gradient sum
 template <typename T>
 __global__ void favor_fix_kernel(const FavorParams p) {
-    const unsigned long long key = *p.kmax;
+    const unsigned long long key = kmax_all(p.kmax, p.kmax_slots, threadIdx.x);      // launched with one wave
     const unsigned long long idx = 0xffffffffull - (key & 0xffffffffull);
     const int mi = idx % p.m;
     const unsigned long long t = idx / p.m;

@@ -107,30 +107,35 @@ __global__ __launch_bounds__(256) void favor_kmax_fast_kernel(const FavorParams 
 #pragma unroll
         for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(wf[mt][kb], W, dh, 16 * mt + li, m, dh, kb, lane);
     unsigned int bestb = 0u, besti = 0u;                      // ordered bits of the lane's largest dd and its flat index
-    Frag<T> xf[DKB];
+    // PF blocks of 16 rows are requested together and then worked through: one block ahead, a wave has 1 KB in flight
+    // and the kernel runs at the latency of its loads (12 waves per CU: ~1.5 TB/s)
+    constexpr int PF = 5;
+    const int lfirst = 16 * (wave + 4 * blockIdx.z), lstep = 64 * gridDim.z;   // grid z: workgroups that share a (b, h)
+    for (int lb = lfirst; lb < L; lb += PF * lstep) {
+        Frag<T> xf[PF][DKB];
 #pragma unroll
-    for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(xf[kb], K, p.ld, 16 * wave + li, L, dh, kb, lane);
-    for (int l0 = 16 * wave; l0 < L; l0 += 64) {
-        Frag<T> xn[DKB];
+        for (int j = 0; j < PF; ++j)
 #pragma unroll
-        for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(xn[kb], K, p.ld, l0 + 64 + li, L, dh, kb, lane);
-        const int l = l0 + li;
-        const unsigned int ibase = (unsigned int)((((unsigned long long)b * L + l) * p.H + h) * m);
+            for (int kb = 0; kb < DKB; ++kb) row_frag_global<T>(xf[j][kb], K, p.ld, lb + j * lstep + li, L, dh, kb, lane);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < PF; ++j) {
+            const int l = lb + j * lstep + li;
+            const unsigned int ibase = (unsigned int)((((unsigned long long)b * L + l) * p.H + h) * m);
 #pragma unroll
-            for (int kb = 0; kb < DKB; ++kb) s = mma(wf[mt][kb], xf[kb], s);     // dd^T[feature 16mt+4g+r][token li]
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mi = 16 * mt + 4 * g + r;
-                const unsigned int ob = (l < L && mi < m) ? ordered_bits(s[r]) : 0u;
-                const bool up = ob > bestb;                   // flat indices grow along the lane's walk: ties keep the first
-                bestb = up ? ob : bestb;
-                besti = up ? ibase + mi : besti;
+                for (int kb = 0; kb < DKB; ++kb) s = mma(wf[mt][kb], xf[j][kb], s);  // dd^T[feature 16mt+4g+r][token li]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mi = 16 * mt + 4 * g + r;
+                    const unsigned int ob = (l < L && mi < m) ? ordered_bits(s[r]) : 0u;
+                    const bool up = ob > bestb;               // flat indices grow along the lane's walk: ties keep the first
+                    bestb = up ? ob : bestb;
+                    besti = up ? ibase + mi : besti;
+                }
             }
         }
-        frag_copy<T, DKB>(xf, xn);
     }
     unsigned long long best = bestb ? (((unsigned long long)bestb << 32) | (0xffffffffull - besti)) : 0ull;
 #pragma unroll
@@ -138,7 +143,16 @@ __global__ __launch_bounds__(256) void favor_kmax_fast_kernel(const FavorParams 
         const unsigned long long other = __shfl_xor(best, o, 64);
         best = other > best ? other : best;
     }
-    if (lane == 0 && best > __atomic_load_n(p.kmax, __ATOMIC_RELAXED)) atomicMax(p.kmax, best);
+    // one visit per workgroup, to the cell its (b, h) hashes to (3072 waves visiting ONE cell were most of this kernel's time)
+    __shared__ unsigned long long wbest[4];
+    if (lane == 0) wbest[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int wv = 1; wv < 4; ++wv) best = wbest[wv] > best ? wbest[wv] : best;
+        unsigned long long* cell = p.kmax + ((b * p.H + h + blockIdx.z) & (KMAX_SLOTS - 1));
+        if (best > __atomic_load_n(cell, __ATOMIC_RELAXED)) atomicMax(cell, best);
+    }
 }
 
 // ------------------------------------------------------------------ KV, ksum
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? (MTC <= 2 ? 3 : 2) : 1) void 
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * L * p.ld + h * dh;
     const T* W = reinterpret_cast<const T*>(p.w);
     float stab = 0.f;
-    if constexpr (KIND == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(*p.kmax >> 32));
+    if constexpr (KIND == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(kmax_all(p.kmax, KMAX_SLOTS, lane) >> 32));
 
     Frag<T> ones;
 #pragma unroll
@@ -675,7 +689,7 @@ __global__ __launch_bounds__(256) void favor_bwd_kv_fast_kernel(const FavorParam
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * L * p.ld + h * dh;
     float stab = 0.f;
-    if constexpr (KIND == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(*p.kmax >> 32));
+    if constexpr (KIND == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(kmax_all(p.kmax, KMAX_SLOTS, lane) >> 32));
     const int g0 = blockIdx.x * p.groups, g1 = min(g0 + p.groups, (L + 63) / 64);
     Frag<T> xf[DKB], vf[DKB];
 #pragma unroll
@@ -797,6 +811,7 @@ template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorP
     constexpr int MT = 4, MTC = 2;        // MTC: feature tiles per workgroup of the KV kernel
     using F = FastCfg<T, DKB, MT>;
     FavorParams p = p0;
+    p.kmax_slots = KMAX_SLOTS;
     const int ng = (p.L + 63) / 64;
     static bool attr = false;
     if (!attr) {
@@ -808,11 +823,11 @@ template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorP
     }
     if (!bwd) {
         if (KIND == FAVOR_SOFTMAX) {
-            (void)vitk_zero_async(p.kmax, 8, 8, 1, st);
-            hipLaunchKernelGGL((favor_kmax_fast_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), 0, st, p);
+            (void)vitk_zero_async(p.kmax, 8 * KMAX_SLOTS, 8 * KMAX_SLOTS, 1, st);
+            hipLaunchKernelGGL((favor_kmax_fast_kernel<T, DKB, MT>), dim3(p.H, p.B, 1), dim3(256), 0, st, p);
         }
         hipLaunchKernelGGL((favor_kv_fast_kernel<T, DKB, MT, MTC, KIND, POS>), dim3(p.H, p.B, MT / MTC), dim3(256), F::kv_bytes(MTC), st, p);
-        p.groups = pick_groups(p, 1536);
+        p.groups = pick_groups(p, 3072);
         hipLaunchKernelGGL((favor_out_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
                            dim3(256), F::out_bytes, st, p);
     } else {
