@@ -463,18 +463,24 @@ __global__ __launch_bounds__(256, MT <= 4 ? 2 : 1) void favor_bwd_q_kernel(const
         wave_lds_sync();
     }
     // reduce over the 4 waves and write dKV in both layouts (+ fp32 transposed copy) and dksum
+    // the four waves add in turn, with plain LDS reads and writes: LDS float atomics from four waves onto the same
+    // 4 K addresses took ~40 us per workgroup (most of this kernel's fixed cost)
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        float s = dks[mt];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (g == 0) atomicAdd(&dksr[16 * mt + li], s);
+            for (int mt = 0; mt < MT; ++mt) {
+                float s = dks[mt];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (g == 0) dksr[16 * mt + li] += s;
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
+                for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li], dkvt[dt][mt][r]);
+                    for (int r = 0; r < 4; ++r) red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li] += dkvt[dt][mt][r];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     T* DKVT = reinterpret_cast<T*>(p.dkvt_t) + ((long)b * p.H + h) * dh * p.mp;
     T* DKV = reinterpret_cast<T*>(p.dkv_t) + ((long)b * p.H + h) * p.mp * p.dhp;
     float* DKS = p.dksum + ((long)b * p.H + h) * p.mp;

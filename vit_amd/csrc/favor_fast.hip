@@ -65,11 +65,15 @@ __device__ __forceinline__ void stage_t(T* img, const T* __restrict__ XT, int dh
 
 // fp32 [mp][dhp] (global) -> bf16 hi / lo images [MP][DLD] x 2 (x ~ hi + lo), or one fp32 image [MP][WLD]
 template <typename T, int DKB, int MT>
-__device__ __forceinline__ void stage_hilo(char* img, const float* __restrict__ X32, int dhp, int tid) {
+__device__ __forceinline__ void stage_hilo(char* img, const float* __restrict__ X32, int dhp, int tid, T* imgT = nullptr) {
     using F = FastCfg<T, DKB, MT>;
     for (int c = tid; c < F::MP * (F::DHP / 4); c += 256) {
         const int mm = c / (F::DHP / 4), d0 = (c - mm * (F::DHP / 4)) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(X32 + (long)mm * dhp + d0);
+        if (imgT) {                                               // and X^T in T: [DHP][WTLD]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) imgT[(d0 + j) * F::WTLD + mm] = from_f32<T>(v[j]);
+        }
         if constexpr (sizeof(T) == 2) {
             __bf16* hi = reinterpret_cast<__bf16*>(img) + mm * F::DLD + d0;
             bf16x4 vh, vl;
@@ -445,9 +449,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
             if (l0 + r < L && d < dh) dr[j] = *reinterpret_cast<const u32x4*>(DO + (long)(l0 + r) * p.ldo + d);
         }
     };
-    fetch(16 * wave, xf, of, doraw);
+    const int lfirst = 16 * (wave + 4 * blockIdx.z), lstep = 64 * gridDim.z;   // grid z: workgroups sharing a (b, h)
+    fetch(lfirst, xf, of, doraw);
 
-    for (int l0 = 16 * wave; l0 < L; l0 += 64) {
+    for (int l0 = lfirst; l0 < L; l0 += lstep) {
         const int l = l0 + li;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
         wave_lds_sync();
         Frag<T> xn[DKB], on[DKB];
         u32x4 dorawn[NCH];
-        fetch(l0 + 64 < L ? l0 + 64 : L, xn, on, dorawn);        // past the end: zeros, no loads
+        fetch(l0 + lstep < L ? l0 + lstep : L, xn, on, dorawn);  // past the end: zeros, no loads
         // ---- phase A: lane = token -------------------------------------------------------------
         f32x4 dd[MT];
 #pragma unroll
@@ -638,28 +643,32 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
         for (int j = 0; j < NCH; ++j) doraw[j] = dorawn[j];
     }
     // reduce over the 4 waves and write dKV in both layouts (+ fp32 transposed copy) and dksum
+    // the four waves add in turn, with plain LDS reads and writes: LDS float atomics from four waves onto the same
+    // 4 K addresses took ~40 us per workgroup (most of this kernel's fixed cost)
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        float s = dks[mt];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (g == 0) atomicAdd(&dksr[16 * mt + li], s);
+            for (int mt = 0; mt < MT; ++mt) {
+                float s = dks[mt];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (g == 0) dksr[16 * mt + li] += s;
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
+                for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li], dkvt[dt][mt][r]);
+                    for (int r = 0; r < 4; ++r) red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li] += dkvt[dt][mt][r];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    T* DKVT = reinterpret_cast<T*>(p.dkvt_t) + bh * dh * p.mp;
-    T* DKV = reinterpret_cast<T*>(p.dkv_t) + bh * p.mp * p.dhp;
-    for (int i = tid; i < DHP * MP; i += 256) {
-        const int d = i / MP, mm = i - d * MP;
-        const float v = d < dh ? red[d * RLD + mm] : 0.f;
-        if (d < dh) DKVT[(long)d * p.mp + mm] = from_f32<T>(v);
-        DKV[(long)mm * p.dhp + d] = from_f32<T>(v);
-        p.dkv32[(bh * p.mp + mm) * p.dhp + d] = v;
+    // dKV and dksum leave as fp32 sums only (the key-side kernel makes its bf16 images from them).  The gridDim.z
+    // workgroups of a (b, h) add into zero-filled memory: with two of them the sum does not depend on who comes first.
+    float* DKV32 = p.dkv32 + bh * p.mp * p.dhp;
+    for (int i = tid; i < MP * DHP; i += 256) {
+        const int mm = i / DHP, d = i - mm * DHP;
+        if (d < dh) atomicAdd(DKV32 + (long)mm * p.dhp + d, red[d * RLD + mm]);
     }
-    for (int i = tid; i < MP; i += 256) p.dksum[bh * p.mp + i] = dksr[i];
+    for (int i = tid; i < MP; i += 256) atomicAdd(p.dksum + bh * p.mp + i, dksr[i]);
 }
 
 // ------------------------------------------------------------------ backward, key / value side
@@ -681,8 +690,7 @@ __global__ __launch_bounds__(256) void favor_bwd_kv_fast_kernel(const FavorParam
     float* dks = reinterpret_cast<float*>(dimg + F::hilo_bytes);
     const long bh = (long)b * p.H + h;
     stage_w<T, DKB, MT>(wr, wT, reinterpret_cast<const T*>(p.w), m, dh, tid);
-    stage_t<T, DKB, MT>(dkvT, reinterpret_cast<const T*>(p.dkvt_t) + bh * dh * p.mp, dh, p.mp, tid);
-    stage_hilo<T, DKB, MT>(dimg, p.dkv32 + bh * p.mp * p.dhp, p.dhp, tid);
+    stage_hilo<T, DKB, MT>(dimg, p.dkv32 + bh * p.mp * p.dhp, p.dhp, tid, dkvT);   // both from the fp32 sums (rows d >= dh: 0)
     for (int i = tid; i < MP; i += 256) dks[i] = p.dksum[bh * p.mp + i];
     __syncthreads();
 
@@ -831,8 +839,12 @@ template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorP
         hipLaunchKernelGGL((favor_out_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
                            dim3(256), F::out_bytes, st, p);
     } else {
-        if (KIND == FAVOR_SOFTMAX) (void)vitk_zero_async(p.esum, 4 * (size_t)p.nesum, 4 * (size_t)p.nesum, 1, st);
-        hipLaunchKernelGGL((favor_bwd_q_fast_kernel<T, DKB, MT, KIND, POS>), dim3(p.H, p.B), dim3(256), F::bwd_q_bytes, st, p);
+        // dKV fp32 and the esum cells behind it (one stretch of the workspace), and dksum: the query-side workgroups add
+        const size_t zb = (size_t)(reinterpret_cast<char*>(p.esum) - reinterpret_cast<char*>(p.dkv32)) + 4 * (size_t)p.nesum;
+        (void)vitk_zero_async(p.dkv32, zb, zb, 1, st);
+        (void)vitk_zero_async(p.dksum, 4 * (size_t)p.B * p.H * p.mp, 4 * (size_t)p.B * p.H * p.mp, 1, st);
+        // two workgroups per (b, h): 1536 of them run in three full rounds of two per CU; 768 ran in a round and a half
+        hipLaunchKernelGGL((favor_bwd_q_fast_kernel<T, DKB, MT, KIND, POS>), dim3(p.H, p.B, 2), dim3(256), F::bwd_q_bytes, st, p);
         p.groups = pick_groups(p, 768);
         hipLaunchKernelGGL((favor_bwd_kv_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
                            dim3(256), F::bwd_kv_bytes, st, p);
