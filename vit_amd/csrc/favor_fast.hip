@@ -288,12 +288,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? (MTC <= 2 ? 3 : 2) : 1) void 
     }
     T* KVT = reinterpret_cast<T*>(p.kvt) + bh * dh * p.mp;
     T* KV = reinterpret_cast<T*>(p.kv) + bh * p.mp * p.dhp;
-    for (int i = tid; i < DHP * MPC; i += 256) {
-        const int d = i / MPC, mm = i - d * MPC;
-        const float v = d < dh ? red[d * RLD + mm] : 0.f;
-        if (d < dh) KVT[(long)d * p.mp + mc0 + mm] = from_f32<T>(v);
-        KV[(long)(mc0 + mm) * p.dhp + d] = from_f32<T>(v);
-        p.kv32[(bh * p.mp + mc0 + mm) * p.dhp + d] = v;
+    // each layout written along ITS rows, four elements per lane (one loop over (d, m) for all three left two of them
+    // as 2- and 4-byte stores a row apart per lane: 16 of this kernel's 54 us)
+    for (int i = tid; i < dh * (MPC / 4); i += 256) {
+        const int d = i / (MPC / 4), m4 = (i - d * (MPC / 4)) * 4;
+        store4<T>(KVT + (long)d * p.mp + mc0 + m4, *reinterpret_cast<const f32x4*>(red + d * RLD + m4));
+    }
+    for (int i = tid; i < MPC * (DHP / 4); i += 256) {
+        const int mm = i / (DHP / 4), d4 = (i - mm * (DHP / 4)) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = d4 + j < dh ? red[(d4 + j) * RLD + mm] : 0.f;
+        store4<T>(KV + (long)(mc0 + mm) * p.dhp + d4, v);
+        *reinterpret_cast<f32x4*>(p.kv32 + (bh * p.mp + mc0 + mm) * p.dhp + d4) = v;
     }
     for (int i = tid; i < MPC; i += 256) p.ksum[bh * p.mp + mc0 + i] = ksr[i];
 }
@@ -449,10 +456,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
             if (l0 + r < L && d < dh) dr[j] = *reinterpret_cast<const u32x4*>(DO + (long)(l0 + r) * p.ldo + d);
         }
     };
-    const int lfirst = 16 * (wave + 4 * blockIdx.z), lstep = 64 * gridDim.z;   // grid z: workgroups sharing a (b, h)
-    fetch(lfirst, xf, of, doraw);
+    fetch(16 * wave, xf, of, doraw);
 
-    for (int l0 = lfirst; l0 < L; l0 += lstep) {
+    for (int l0 = 16 * wave; l0 < L; l0 += 64) {
         const int l = l0 + li;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
         wave_lds_sync();
         Frag<T> xn[DKB], on[DKB];
         u32x4 dorawn[NCH];
-        fetch(l0 + lstep < L ? l0 + lstep : L, xn, on, dorawn);  // past the end: zeros, no loads
+        fetch(l0 + 64 < L ? l0 + 64 : L, xn, on, dorawn);        // past the end: zeros, no loads
         // ---- phase A: lane = token -------------------------------------------------------------
         f32x4 dd[MT];
 #pragma unroll
@@ -661,14 +667,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
         }
         __syncthreads();
     }
-    // dKV and dksum leave as fp32 sums only (the key-side kernel makes its bf16 images from them).  The gridDim.z
-    // workgroups of a (b, h) add into zero-filled memory: with two of them the sum does not depend on who comes first.
+    // dKV and dksum leave as fp32 sums only: the key-side kernel makes its bf16 images (both layouts) from them
     float* DKV32 = p.dkv32 + bh * p.mp * p.dhp;
-    for (int i = tid; i < MP * DHP; i += 256) {
-        const int mm = i / DHP, d = i - mm * DHP;
-        if (d < dh) atomicAdd(DKV32 + (long)mm * p.dhp + d, red[d * RLD + mm]);
+    for (int i = tid; i < MP * (DHP / 4); i += 256) {
+        const int mm = i / (DHP / 4), d4 = (i - mm * (DHP / 4)) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = d4 + j < dh ? red[(d4 + j) * RLD + mm] : 0.f;
+        *reinterpret_cast<f32x4*>(DKV32 + (long)mm * p.dhp + d4) = v;
     }
-    for (int i = tid; i < MP; i += 256) atomicAdd(p.dksum + bh * p.mp + i, dksr[i]);
+    for (int i = tid; i < MP; i += 256) p.dksum[bh * p.mp + i] = dksr[i];
 }
 
 // ------------------------------------------------------------------ backward, key / value side
@@ -839,12 +847,10 @@ template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorP
         hipLaunchKernelGGL((favor_out_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
                            dim3(256), F::out_bytes, st, p);
     } else {
-        // dKV fp32 and the esum cells behind it (one stretch of the workspace), and dksum: the query-side workgroups add
-        const size_t zb = (size_t)(reinterpret_cast<char*>(p.esum) - reinterpret_cast<char*>(p.dkv32)) + 4 * (size_t)p.nesum;
-        (void)vitk_zero_async(p.dkv32, zb, zb, 1, st);
-        (void)vitk_zero_async(p.dksum, 4 * (size_t)p.B * p.H * p.mp, 4 * (size_t)p.B * p.H * p.mp, 1, st);
-        // two workgroups per (b, h): 1536 of them run in three full rounds of two per CU; 768 ran in a round and a half
-        hipLaunchKernelGGL((favor_bwd_q_fast_kernel<T, DKB, MT, KIND, POS>), dim3(p.H, p.B, 2), dim3(256), F::bwd_q_bytes, st, p);
+        if (KIND == FAVOR_SOFTMAX) (void)vitk_zero_async(p.esum, 4 * (size_t)p.nesum, 4 * (size_t)p.nesum, 1, st);
+        // one workgroup per (b, h).  Two (fp32 sums added into zeroed memory: still order-independent) were measured: 112.6
+        // us against 105.9 -- the fixed cost per workgroup outweighs the even rounds
+        hipLaunchKernelGGL((favor_bwd_q_fast_kernel<T, DKB, MT, KIND, POS>), dim3(p.H, p.B), dim3(256), F::bwd_q_bytes, st, p);
         p.groups = pick_groups(p, 768);
         hipLaunchKernelGGL((favor_bwd_kv_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
                            dim3(256), F::bwd_kv_bytes, st, p);
