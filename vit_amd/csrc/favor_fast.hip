@@ -37,7 +37,7 @@ template <typename T, int DKB, int MT>
 __device__ __forceinline__ void stage_w(T* wr, T* wT, const T* __restrict__ W, int m, int dh, int tid) {
     using F = FastCfg<T, DKB, MT>;
     constexpr int CPR = F::DHP / F::EPC;
-    for (int c = tid; c < F::MP * CPR; c += 256) {
+    for (int c = tid; c < F::MP * CPR; c += blockDim.x) {
         const int mm = c / CPR, d0 = (c - mm * CPR) * F::EPC;
         u32x4 raw = {0, 0, 0, 0};
         if (mm < m && d0 < dh) raw = *reinterpret_cast<const u32x4*>(W + (long)mm * dh + d0);
@@ -55,7 +55,7 @@ template <typename T, int DKB, int MT>
 __device__ __forceinline__ void stage_t(T* img, const T* __restrict__ XT, int dh, int mp, int tid) {
     using F = FastCfg<T, DKB, MT>;
     constexpr int CPR = F::MP / F::EPC;
-    for (int c = tid; c < F::DHP * CPR; c += 256) {
+    for (int c = tid; c < F::DHP * CPR; c += blockDim.x) {
         const int d = c / CPR, m0 = (c - d * CPR) * F::EPC;
         u32x4 raw = {0, 0, 0, 0};
         if (d < dh) raw = *reinterpret_cast<const u32x4*>(XT + (long)d * mp + m0);
@@ -67,7 +67,7 @@ __device__ __forceinline__ void stage_t(T* img, const T* __restrict__ XT, int dh
 template <typename T, int DKB, int MT>
 __device__ __forceinline__ void stage_hilo(char* img, const float* __restrict__ X32, int dhp, int tid, T* imgT = nullptr) {
     using F = FastCfg<T, DKB, MT>;
-    for (int c = tid; c < F::MP * (F::DHP / 4); c += 256) {
+    for (int c = tid; c < F::MP * (F::DHP / 4); c += blockDim.x) {
         const int mm = c / (F::DHP / 4), d0 = (c - mm * (F::DHP / 4)) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(X32 + (long)mm * dhp + d0);
         if (imgT) {                                               // and X^T in T: [DHP][WTLD]
@@ -680,10 +680,15 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
 }
 
 // ------------------------------------------------------------------ backward, key / value side
-// grid (ceil(groups of 64 tokens / p.groups), H, B); lane = token (see favor_bwd_kv_kernel for the algebra).
+// grid (ceil(groups of 16 * NW tokens / p.groups), H, B), NW waves; lane = token (see favor_bwd_kv_kernel for the
+// algebra).  bf16: eight waves share one set of staged images, so two workgroups put four waves on a SIMD (with four
+// waves per workgroup the 46 KB of images allowed three).
+template <typename T> struct BkvWaves { static constexpr int NW = sizeof(T) == 2 ? 8 : 4; };
+
 template <typename T, int DKB, int MT, int KIND, bool POS>
-__global__ __launch_bounds__(256) void favor_bwd_kv_fast_kernel(const FavorParams p) {
+__global__ __launch_bounds__(BkvWaves<T>::NW * 64) void favor_bwd_kv_fast_kernel(const FavorParams p) {
     using F = FastCfg<T, DKB, MT>;
+    constexpr int NW = BkvWaves<T>::NW, GT = 16 * NW;     // waves per workgroup, tokens per group
     constexpr int ND = 2 * DKB;
     constexpr int MP = F::MP, DHP = F::DHP, WLD = F::WLD, WTLD = F::WTLD, DLD = F::DLD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -699,27 +704,27 @@ __global__ __launch_bounds__(256) void favor_bwd_kv_fast_kernel(const FavorParam
     const long bh = (long)b * p.H + h;
     stage_w<T, DKB, MT>(wr, wT, reinterpret_cast<const T*>(p.w), m, dh, tid);
     stage_hilo<T, DKB, MT>(dimg, p.dkv32 + bh * p.mp * p.dhp, p.dhp, tid, dkvT);   // both from the fp32 sums (rows d >= dh: 0)
-    for (int i = tid; i < MP; i += 256) dks[i] = p.dksum[bh * p.mp + i];
+    for (int i = tid; i < MP; i += 64 * NW) dks[i] = p.dksum[bh * p.mp + i];
     __syncthreads();
 
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * L * p.ld + h * dh;
     float stab = 0.f;
     if constexpr (KIND == FAVOR_SOFTMAX) stab = unordered_bits((unsigned int)(kmax_all(p.kmax, KMAX_SLOTS, lane) >> 32));
-    const int g0 = blockIdx.x * p.groups, g1 = min(g0 + p.groups, (L + 63) / 64);
+    const int g0 = blockIdx.x * p.groups, g1 = min(g0 + p.groups, (L + GT - 1) / GT);
     Frag<T> xf[DKB], vf[DKB];
 #pragma unroll
     for (int kb = 0; kb < DKB; ++kb) {
-        row_frag_global<T>(xf[kb], K, p.ld, g0 * 64 + 16 * wave + li, L, dh, kb, lane);
-        row_frag_global<T>(vf[kb], V, p.ld, g0 * 64 + 16 * wave + li, L, dh, kb, lane);
+        row_frag_global<T>(xf[kb], K, p.ld, g0 * GT + 16 * wave + li, L, dh, kb, lane);
+        row_frag_global<T>(vf[kb], V, p.ld, g0 * GT + 16 * wave + li, L, dh, kb, lane);
     }
     float esum_w = 0.f;
     for (int grp = g0; grp < g1; ++grp) {
-        const int l0 = grp * 64 + 16 * wave, l = l0 + li;
+        const int l0 = grp * GT + 16 * wave, l = l0 + li;
         Frag<T> xn[DKB], vn[DKB];
 #pragma unroll
         for (int kb = 0; kb < DKB; ++kb) {
-            const int ln = grp + 1 < g1 ? l + 64 : L;         // past the end: zero fragments, no load
+            const int ln = grp + 1 < g1 ? l + GT : L;         // past the end: zero fragments, no load
             row_frag_global<T>(xn[kb], K, p.ld, ln, L, dh, kb, lane);
             row_frag_global<T>(vn[kb], V, p.ld, ln, L, dh, kb, lane);
         }
@@ -851,9 +856,11 @@ template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorP
         // one workgroup per (b, h).  Two (fp32 sums added into zeroed memory: still order-independent) were measured: 112.6
         // us against 105.9 -- the fixed cost per workgroup outweighs the even rounds
         hipLaunchKernelGGL((favor_bwd_q_fast_kernel<T, DKB, MT, KIND, POS>), dim3(p.H, p.B), dim3(256), F::bwd_q_bytes, st, p);
-        p.groups = pick_groups(p, 768);
-        hipLaunchKernelGGL((favor_bwd_kv_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
-                           dim3(256), F::bwd_kv_bytes, st, p);
+        constexpr int NWK = BkvWaves<T>::NW;
+        const int ngk = (p.L + 16 * NWK - 1) / (16 * NWK);
+        p.groups = (int)std::max(1L, std::min((long)ngk, (long)p.B * p.H * ngk / (NWK == 8 ? 512 : 768)));
+        hipLaunchKernelGGL((favor_bwd_kv_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ngk + p.groups - 1) / p.groups, p.H, p.B),
+                           dim3(64 * NWK), F::bwd_kv_bytes, st, p);
         if (KIND == FAVOR_SOFTMAX) hipLaunchKernelGGL(favor_fix_kernel<T>, dim3(1), dim3(64), 0, st, p);
     }
 }
