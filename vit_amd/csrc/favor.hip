@@ -815,13 +815,12 @@ template <typename T, int DKB> void dispatch_mt(const FavorParams& p, bool bwd, 
         if (bwd) launch_bwd<T, DKB, M>(p, st);      \
         else launch_fwd<T, DKB, M>(p, st);          \
     } while (0)
-    if (mt == 1) VITK_FV(1);
-    else VITK_FV(16);          // mt == 4 never gets here (favor_fast.hip)
+    VITK_FV(16);               // mt == 1 and 4 never get here (favor_fast.hip)
 #undef VITK_FV
 }
 
 void dispatch(const FavorParams& p, int dtype, bool bwd, hipStream_t st) {
-    if (favor_fast_launch(p, dtype, bwd, st)) return;          // 17..64 features: favor_fast.hip
+    if (favor_fast_launch(p, dtype, bwd, st)) return;          // up to 64 features: favor_fast.hip
     const int dkb = (p.dh + 31) / 32;
     if (dtype == VITK_BF16) {
         if (dkb == 1) dispatch_mt<__bf16, 1>(p, bwd, st);

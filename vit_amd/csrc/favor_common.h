@@ -1,5 +1,5 @@
 // FAVOR+ kernels: parameter block and device helpers shared by favor.hip (every shape) and favor_fast.hip
-// (17..64 random features: per-(b, h) operands staged in LDS).  See favor.hip for the algorithm.
+// (up to 64 random features: per-(b, h) operands staged in LDS).  See favor.hip for the algorithm.
 #pragma once
 #include "attn_common.h"
 
@@ -179,7 +179,7 @@ __global__ void favor_fix_kernel(const FavorParams p) {
         DK[d] = from_f32<T>(to_f32<T>(DK[d]) - s * to_f32<T>(W[(long)mi * p.dh + d]));
 }
 
-// favor_fast.hip: launches the forward / backward for 17..64 features (mp == 64); false when the shape is not its
+// favor_fast.hip: launches the forward / backward for up to 64 features (mp == 16 or 64); false when the shape is not its
 bool favor_fast_launch(const FavorParams& p, int dtype, bool bwd, hipStream_t st);
 
 }  // namespace vitk

@@ -1,6 +1,6 @@
-// FAVOR+ for 17..64 random features (feature pitch mp = 64: four 16-wide tiles), the shape of the reference's
-// configurations (nb_features = 64; timm_classes/timm_vision_performer.py:26-101, model.py:257-352).  Same algorithm,
-// workspace and results as the kernels of favor.hip (which keep m <= 16 and m > 64); what differs is where the
+// FAVOR+ for up to 64 random features (feature pitch mp = 16 or 64: one or four 16-wide tiles), the shapes of the
+// reference's configurations (nb_features = 16 by default, train.py:75; 64: timm_classes/timm_vision_performer.py:26-101, model.py:257-352).  Same algorithm,
+// workspace and results as the kernels of favor.hip (which keep m > 64); what differs is where the
 // operands live:
 //   - everything that belongs to a (b, h) rather than to a token -- w row-major and transposed, KV / dKV as bf16
 //     hi / lo images, KV^T / dKV^T, ksum / dksum -- is staged in LDS once per workgroup (the plain kernels fetch ~45
@@ -828,8 +828,8 @@ int pick_groups(const FavorParams& p, long want) {
     return (int)std::max(1L, std::min(ng, (long)p.B * p.H * ng / want));
 }
 
-template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorParams& p0, bool bwd, hipStream_t st) {
-    constexpr int MT = 4, MTC = 2;        // MTC: feature tiles per workgroup of the KV kernel
+template <typename T, int DKB, int MT, int KIND, bool POS> void launch_fast(const FavorParams& p0, bool bwd, hipStream_t st) {
+    constexpr int MTC = MT >= 4 ? 2 : 1;   // feature tiles per workgroup of the KV kernel
     using F = FastCfg<T, DKB, MT>;
     FavorParams p = p0;
     p.kmax_slots = KMAX_SLOTS;
@@ -865,28 +865,33 @@ template <typename T, int DKB, int KIND, bool POS> void launch_fast(const FavorP
     }
 }
 
-template <typename T, int DKB> void fast_kind(const FavorParams& p, bool bwd, hipStream_t st) {
+template <typename T, int DKB, int MT> void fast_kind(const FavorParams& p, bool bwd, hipStream_t st) {
     const bool pos = p.pq != nullptr;
     if (p.kind == FAVOR_SOFTMAX) {
-        if (pos) launch_fast<T, DKB, FAVOR_SOFTMAX, true>(p, bwd, st);
-        else launch_fast<T, DKB, FAVOR_SOFTMAX, false>(p, bwd, st);
+        if (pos) launch_fast<T, DKB, MT, FAVOR_SOFTMAX, true>(p, bwd, st);
+        else launch_fast<T, DKB, MT, FAVOR_SOFTMAX, false>(p, bwd, st);
     } else {
-        if (pos) launch_fast<T, DKB, FAVOR_RELU, true>(p, bwd, st);
-        else launch_fast<T, DKB, FAVOR_RELU, false>(p, bwd, st);
+        if (pos) launch_fast<T, DKB, MT, FAVOR_RELU, true>(p, bwd, st);
+        else launch_fast<T, DKB, MT, FAVOR_RELU, false>(p, bwd, st);
     }
+}
+
+template <typename T, int DKB> void fast_mt(const FavorParams& p, bool bwd, hipStream_t st) {
+    if (p.mp == 16) fast_kind<T, DKB, 1>(p, bwd, st);
+    else fast_kind<T, DKB, 4>(p, bwd, st);
 }
 
 }  // namespace
 
 bool favor_fast_launch(const FavorParams& p, int dtype, bool bwd, hipStream_t st) {
-    if (p.mp != 64) return false;
+    if (p.mp != 16 && p.mp != 64) return false;
     const int dkb = (p.dh + 31) / 32;
     if (dtype == VITK_BF16) {
-        if (dkb == 1) fast_kind<__bf16, 1>(p, bwd, st);
-        else fast_kind<__bf16, 2>(p, bwd, st);
+        if (dkb == 1) fast_mt<__bf16, 1>(p, bwd, st);
+        else fast_mt<__bf16, 2>(p, bwd, st);
     } else {
-        if (dkb == 1) fast_kind<float, 1>(p, bwd, st);
-        else fast_kind<float, 2>(p, bwd, st);
+        if (dkb == 1) fast_mt<float, 1>(p, bwd, st);
+        else fast_mt<float, 2>(p, bwd, st);
     }
     return true;
 }
