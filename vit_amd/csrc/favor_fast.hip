@@ -95,6 +95,41 @@ template <typename T, int DKB> __device__ __forceinline__ void frag_copy(Frag<T>
     for (int kb = 0; kb < DKB; ++kb) d[kb] = s[kb];
 }
 
+// Sum of the four waves' accumulator tiles acc[dt][mt][r] = X[16 dt + 4 g + r][16 mt + li] (+ a per-column scalar sv[mt])
+// into red[row * RLD + col] and sums[col] (sums = red + 16 ND * RLD): waves 0 and 1 store into two copies (redB lies
+// over LDS the loop no longer needs), waves 2 and 3 add to them, everybody adds copy B to copy A.  Plain LDS
+// operations in a fixed order: bit-reproducible, two hand-offs instead of four, nothing to zero beforehand.
+template <int ND, int MTN, int RLD>
+__device__ __forceinline__ void wave_quad_sum(float* red, float* redB, const f32x4 (&acc)[ND][MTN], const float (&sv)[MTN],
+                                              int wave, int lane, int tid) {
+    const int g = lane >> 4, li = lane & 15;
+    constexpr int NR = 16 * ND * RLD;
+    __syncthreads();                        // every wave has left the loop
+#pragma unroll
+    for (int turn = 0; turn < 2; ++turn) {
+        if ((wave >> 1) == turn) {
+            float* r = (wave & 1) ? redB : red;
+#pragma unroll
+            for (int mt = 0; mt < MTN; ++mt) {
+                float s = sv[mt];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (g == 0) r[NR + 16 * mt + li] = turn ? r[NR + 16 * mt + li] + s : s;
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float* c = r + (16 * dt + 4 * g + q) * RLD + 16 * mt + li;
+                        *c = turn ? *c + acc[dt][mt][q] : acc[dt][mt][q];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < NR + 16 * MTN; i += 256) red[i] += redB[i];
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ global key max (+ argmax)
 // grid (H, B): w fragments stay in registers, the next 16 K rows are in flight during the products.
 template <typename T, int DKB, int MT>
@@ -179,8 +214,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? (MTC <= 2 ? 3 : 2) : 1) void 
     T* Vw = reinterpret_cast<T*>(smem) + wave * 32 * ASTR;
     float* red = reinterpret_cast<float*>(reinterpret_cast<T*>(smem) + 4 * 32 * ASTR);   // [DHP][RLD] + ksum[MPC]
     float* ksr = red + DHP * RLD;
-    for (int i = tid; i < DHP * RLD + MPC; i += 256) red[i] = 0.f;
-    __syncthreads();
+    static_assert((size_t)4 * 32 * ASTR * sizeof(T) >= (size_t)(DHP * RLD + MPC) * 4, "second copy of the sums over the V images");
 
     const T* K = reinterpret_cast<const T*>(p.k) + (long)b * L * p.ld + h * dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (long)b * L * p.ld + h * dh;
@@ -269,23 +303,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? (MTC <= 2 ? 3 : 2) : 1) void 
 #pragma unroll
         for (int j = 0; j < NV; ++j) vraw[j] = vrawn[j];
     }
-    // reduce the 4 waves, one after the other (a fixed order: the forward is bit-reproducible)
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
-#pragma unroll
-            for (int mt = 0; mt < MTC; ++mt) {
-                float s = ks[mt];
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                if (g == 0) ksr[16 * mt + li] += s;
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li] += acc[dt][mt][r];
-            }
-        }
-        __syncthreads();
-    }
+    // the four waves' sums, in a fixed order (the forward is bit-reproducible)
+    wave_quad_sum<ND, MTC, RLD>(red, reinterpret_cast<float*>(smem), acc, ks, wave, lane, tid);
     T* KVT = reinterpret_cast<T*>(p.kvt) + bh * dh * p.mp;
     T* KV = reinterpret_cast<T*>(p.kv) + bh * p.mp * p.dhp;
     // each layout written along ITS rows, four elements per lane (one loop over (d, m) for all three left two of them
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
 
     stage_w<T, DKB, MT>(wr, wT, reinterpret_cast<const T*>(p.w), m, dh, tid);
     stage_hilo<T, DKB, MT>(kvimg, p.kv32 + bh * p.mp * p.dhp, p.dhp, tid);
-    for (int i = tid; i < DHP * RLD + MP; i += 256) red[i] = 0.f;
+    static_assert((size_t)(MP * WLD + DHP * WTLD) * sizeof(T) >= (size_t)(DHP * RLD + MP) * 4, "second copy of the sums over the w images");
     for (int i = tid; i < MP; i += 256) ks[i] = p.ksum[bh * p.mp + i];
     __syncthreads();
 
@@ -649,24 +668,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void favor_bwd_q_fast_
         for (int j = 0; j < NCH; ++j) doraw[j] = dorawn[j];
     }
     // reduce over the 4 waves and write dKV in both layouts (+ fp32 transposed copy) and dksum
-    // the four waves add in turn, with plain LDS reads and writes: LDS float atomics from four waves onto the same
-    // 4 K addresses took ~40 us per workgroup (most of this kernel's fixed cost)
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float s = dks[mt];
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                if (g == 0) dksr[16 * mt + li] += s;
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[(16 * dt + 4 * g + r) * RLD + 16 * mt + li] += dkvt[dt][mt][r];
-            }
-        }
-        __syncthreads();
-    }
+    // the four waves' sums (plain LDS adds: LDS float atomics from four waves onto the same 4 K addresses took ~40 us)
+    wave_quad_sum<ND, MT, RLD>(red, reinterpret_cast<float*>(smem), dkvt, dks, wave, lane, tid);
     // dKV and dksum leave as fp32 sums only: the key-side kernel makes its bf16 images (both layouts) from them
     float* DKV32 = p.dkv32 + bh * p.mp * p.dhp;
     for (int i = tid; i < MP * (DHP / 4); i += 256) {
