@@ -195,7 +195,10 @@ __global__ __launch_bounds__(256) void favor_kmax_fast_kernel(const FavorParams 
 }
 
 // ------------------------------------------------------------------ KV, ksum
-// grid (H, B, MT / MTC); as favor_kv_kernel, with the next 32 K / V rows in flight.  A workgroup owns MTC of the MT
+// grid 8 * ceil(B H / 8) * (MT / MTC), one-dimensional; as favor_kv_kernel, with the next 32 K / V rows in flight.  The
+// MT / MTC workgroups of a (b, h) all read its K and V rows: they get consecutive slots of ONE XCD (workgroup id mod 8
+// is the XCD), so the second reads hit that XCD's L2 -- as a third grid dimension they ran a round apart, on any XCD,
+// and the kernel moved 252 MB per launch for 113 MB of rows (PMC), at 6 TB/s.  A workgroup owns MTC of the MT
 // feature tiles (its own columns of KV: no exchange, the same sums in the same order whatever MTC is): with all four
 // the accumulators take half the register file, two workgroups fit a CU and 768 of them run in a round and a half;
 // with two, 1536 half-sized workgroups run three to a CU in two full rounds.
@@ -208,7 +211,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? (MTC <= 2 ? 3 : 2) : 1) void 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.x, b = blockIdx.y, mc0 = blockIdx.z * MPC;
+    constexpr int NZ = MT / MTC;
+    const int slot = blockIdx.x >> 3, bhi = (slot / NZ) * 8 + (blockIdx.x & 7);
+    if (bhi >= p.B * p.H) return;
+    const int h = bhi % p.H, b = bhi / p.H, mc0 = (slot % NZ) * MPC;
     const int L = p.L, dh = p.dh, m = p.m;
     const long bh = (long)b * p.H + h;
     T* Vw = reinterpret_cast<T*>(smem) + wave * 32 * ASTR;
@@ -850,7 +856,8 @@ template <typename T, int DKB, int MT, int KIND, bool POS> void launch_fast(cons
             (void)vitk_zero_async(p.kmax, 8 * KMAX_SLOTS, 8 * KMAX_SLOTS, 1, st);
             hipLaunchKernelGGL((favor_kmax_fast_kernel<T, DKB, MT>), dim3(p.H, p.B, 1), dim3(256), 0, st, p);
         }
-        hipLaunchKernelGGL((favor_kv_fast_kernel<T, DKB, MT, MTC, KIND, POS>), dim3(p.H, p.B, MT / MTC), dim3(256), F::kv_bytes(MTC), st, p);
+        hipLaunchKernelGGL((favor_kv_fast_kernel<T, DKB, MT, MTC, KIND, POS>), dim3(8 * ((p.B * p.H + 7) / 8) * (MT / MTC)), dim3(256),
+                           F::kv_bytes(MTC), st, p);
         p.groups = pick_groups(p, 3072);
         hipLaunchKernelGGL((favor_out_fast_kernel<T, DKB, MT, KIND, POS>), dim3((ng + p.groups - 1) / p.groups, p.H, p.B),
                            dim3(256), F::out_bytes, st, p);
