@@ -301,3 +301,36 @@ def test_performer_models_run():
         loss.backward()
         assert torch.isfinite(loss).item()
         assert all(torch.isfinite(p.grad).all().item() for p in net.parameters() if p.grad is not None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kernel', ['softmax', 'relu'])
+def test_performer_block_one_node_matches_op_by_op(kernel):
+    """A timm block whose attention was replaced by PerformerAttention (train.py:147-165) runs as ONE autograd node
+    (functional.PreLNBlockFn with FAVOR+ inside: residuals in the GEMM epilogues); the op-by-op form of the same block
+    (layer_norm / linear / favor_attention / mlp nodes, torch adds) is the check: same kernels for everything but the
+    residual adds, so the two agree to a few bf16 roundings."""
+    from vit_amd.timm_classes import timm_locality_aware_transformer as TL
+    from vit_amd.train import build_model
+    torch.manual_seed(0)
+    net = build_model('performer_timm', preset='S', img_size=64, patch_size=16, num_classes=10, depth=2, dim=128,
+                      mlp=256, heads=4, kernel=kernel, num_orf=32)
+    img = torch.randn(4, 3, 64, 64, device='cuda')
+
+    def run(fuse):
+        TL.FUSE_SWAPPED = fuse
+        try:
+            net.zero_grad(set_to_none=True)
+            out = net(img, 0)
+            out.float().square().sum().backward()
+            return out.detach().float().clone(), {n: p.grad.float().clone() for n, p in net.named_parameters() if p.grad is not None}
+        finally:
+            TL.FUSE_SWAPPED = True
+
+    out1, g1 = run(True)
+    out0, g0 = run(False)
+    assert g1.keys() == g0.keys()
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    assert rel(out1, out0) < 2e-2
+    for n in g0:
+        assert rel(g1[n], g0[n]) < 3e-2, n

@@ -430,17 +430,27 @@ def _mlp_bwd(dy, x, w1, w2, act, hmid, pre, residual_grad, db1=None, db2=None, d
 class PreLNBlockFn(torch.autograd.Function):
     """x + proj(attn(LN1(x))) then + mlp(LN2(.)) -- BlockLAI.forward
     (timm_classes/timm_locality_aware_transformer.py:96-99) and, with act='relu' and no band,
-    TransformerEncoderLayer.forward_pre (model.py:194-204)."""
+    TransformerEncoderLayer.forward_pre (model.py:194-204).  cfg = (B, N, H, eps, scale, w, act[, favor]): with
+    favor = (features [m, dh] in compute dtype, kind, ratio, feature eps) the attention is FAVOR+ (a timm block whose
+    attn was replaced by PerformerAttention, train.py:147-165) -- the same node, the saved log-sum-exp replaced by the
+    FAVOR+ workspace."""
 
     @staticmethod
     def forward(ctx, x, g1, be1, wqkv, bqkv, wproj, bproj, g2, be2, w1, b1, w2, b2, cfg):
-        B, N, H, eps, scale, w, act = cfg
+        B, N, H, eps, scale, w, act = cfg[:7]
+        favor = cfg[7] if len(cfg) > 7 else None
         D = x.shape[1]
         dh = D // H
         dt = x.dtype
         h1, mean1, rstd1 = ops.layernorm_fwd(x, _f32(g1), _f32(be1), eps)
         qkv = ops.gemm(h1, shadow(wqkv, dt), bias=_f32(bqkv))
-        attn, lse = _attn_fwd(qkv, B, N, H, dh, None, scale, w)
+        if favor is None:
+            attn, lse = _attn_fwd(qkv, B, N, H, dh, None, scale, w)
+        else:
+            fw, kind, ratio, feps = favor
+            lse = ops.favor_workspace(qkv, B, H, dh, fw.shape[0])          # the op's saved state
+            attn = ops.favor_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, dh, qkv.stride(0), fw, kind, ratio,
+                                 feps, lse)
         x1 = ops.gemm(attn, shadow(wproj, dt), bias=_f32(bproj), residual=x)
         h2, mean2, rstd2 = ops.layernorm_fwd(x1, _f32(g2), _f32(be2), eps)
         y, hmid, pre = _mlp_fwd(h2, shadow(w1, dt), _f32(b1), shadow(w2, dt), _f32(b2), act, x1)
@@ -454,7 +464,8 @@ class PreLNBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x, g1, wqkv, wproj, g2, w1, w2, mean1, rstd1, h1, qkv, attn, lse, x1, mean2, rstd2, h2, hmid,
          pre) = ctx.saved_tensors
-        B, N, H, eps, scale, w, act = ctx.cfg
+        B, N, H, eps, scale, w, act = ctx.cfg[:7]
+        favor = ctx.cfg[7] if len(ctx.cfg) > 7 else None
         D = x.shape[1]
         dh = D // H
         dt = x.dtype
@@ -474,7 +485,15 @@ class PreLNBlockFn(torch.autograd.Function):
         dwproj = _dw(dx1, attn, out=s_wproj if s_wproj is not None else zp.take(D, D), side=True)
         dattn = _dx(dx1, wproj)
         dbqkv = zp.take(3 * D) if ctx.has_qkv_bias else None        # summed by the attention backward itself
-        dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse, dbias=dbqkv)
+        if favor is None:
+            dqkv, _ = _attn_bwd(qkv, B, N, H, dh, None, scale, w, attn, dattn, lse, dbias=dbqkv)
+        else:
+            fw, kind, ratio, feps = favor
+            dqkv = torch.empty_like(qkv)
+            ops.favor_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, dh, qkv.stride(0), fw, kind, ratio, feps,
+                          attn, dattn, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, lse)
+            if dbqkv is not None:
+                ops.colsum(dqkv, out=dbqkv)
         dwqkv = _dw(dqkv, h1, out=s_wqkv if s_wqkv is not None else zp.take(3 * D, D), side=True)
         # a fresh alias of a slab view: autograd adopts it as .grad without a copy
         dw1, dw2, dwproj, dwqkv = (t.detach() if t is s else t

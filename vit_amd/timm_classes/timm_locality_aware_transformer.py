@@ -112,6 +112,9 @@ class AttentionLAI(ComputeDtypeMixin, nn.Module):
         return y.view(B, N, C).to(x.dtype)
 
 
+FUSE_SWAPPED = True      # tests switch it off to compare the one-node block with the op-by-op form
+
+
 class BlockLAI(ComputeDtypeMixin, nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
                  drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, mask_epochs=None):
@@ -132,6 +135,16 @@ class BlockLAI(ComputeDtypeMixin, nn.Module):
         _check_p0(self, self.drop_path_rate)
         p_mlp = self.mlp.drop.p if self.training else 0.
         if not isinstance(a, AttentionLAI):      # an attention swapped in (FAVOR+, train.py:147-165)
+            favor = a.favor_cfg(x2) if hasattr(a, 'favor_cfg') and FUSE_SWAPPED else None
+            drops = self.training and (p_mlp > 0 or a.attn_drop.p > 0 or a.proj_drop.p > 0)
+            if favor is not None and not drops and self.norm1.eps == self.norm2.eps:
+                # the whole block as ONE node, as for AttentionLAI below (residuals in the proj / fc2 epilogues, weight
+                # gradients on the second stream): 33.0 -> see DESIGN.md for the 384-px Performer step
+                cfg = (B, N, a.num_heads, self.norm1.eps, 0.0, -1, 'gelu', favor)
+                return VF.PreLNBlockFn.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
+                                             a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias,
+                                             self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
+                                             self.mlp.fc2.bias, cfg)
             x2 = x2 + a.forward2d(VF.layer_norm(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, N)
             h = VF.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
             return x2 + VF.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,

@@ -80,10 +80,20 @@ class PerformerAttention(ComputeDtypeMixin, Attention):
     def ratio(self):
         return 1.0 / math.sqrt(math.sqrt(self.m))          # both feature maps use m^-1/4 here (:72,96)
 
+    def features(self, device):
+        if self.w is None:
+            self.w = gaussian_orthogonal_random_matrix(self.m, self.head_dim, device=device)
+        return self.w
+
+    def favor_cfg(self, x2):
+        """(features in compute dtype, kind, ratio, eps) for functional.PreLNBlockFn: a block that holds this attention
+        runs as one autograd node."""
+        kind, eps = VF._favor_kind(self.kernel)
+        return self.features(x2.device).to(device=x2.device, dtype=x2.dtype).contiguous(), kind, float(self.ratio()), eps
+
     def forward2d(self, x2, B, N):
         """[B*N, C] in compute dtype -> [B*N, C]."""
-        if self.w is None:
-            self.w = gaussian_orthogonal_random_matrix(self.m, self.head_dim, device=x2.device)
+        self.features(x2.device)
         C = x2.shape[1]
         qkv = VF.linear(x2, self.qkv.weight, self.qkv.bias)
         y = VF.favor_attention(qkv, self.w.to(x2.device), B, N, self.num_heads, C // self.num_heads, self.kernel,
