@@ -88,7 +88,7 @@ def test_attn_bwd(dtype, bias, w, B, N, H, dh):
         pqr = pq.double().view(-1, H, dh).clone().requires_grad_(True)
     ref, _, _ = attention_ref(qr, kr, vr, pkr, pqr, scale, w)
     (ref * dout.double().view(B, N, H, dh)).sum().backward()
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert relerr(dq.reshape(B, N, H, dh), qr.grad) < tol
     assert relerr(dk.reshape(B, N, H, dh), kr.grad) < tol
     assert relerr(dv.reshape(B, N, H, dh), vr.grad) < tol
