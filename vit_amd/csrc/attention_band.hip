@@ -544,16 +544,30 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                 if (qt >= NT) continue;
                 const int qi0 = 16 * qt;
                 const int klo = max(0, qt - c_hi), khi = min(NT - 1, qt - c_lo);
+                // the tile values of the NEXT key-tile pair are asked for before the current pair is worked on (they
+                // come back from L2: one round trip per pair otherwise).  Loads without a condition -- a tile past khi
+                // reads tile khi and is zeroed -- so that the compiler can count them (vmcnt) instead of waiting for all.
+                auto ds_pair = [&](int ka, __bf16 (&raw)[2][4]) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int kt = min(ka + u, khi);
+                        const __bf16* e = ds_head + ((long)(qt - kt + grp.cmax) * NT + kt) * 256 + tr_off;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) raw[u][r] = e[4 * r];
+                    }
+                };
+                __bf16 cur[2][4], nxt[2][4];
+                if (klo <= khi) ds_pair(klo, cur);
                 for (int ka = klo; ka <= khi; ka += 2) {
+                    ds_pair(min(ka + 2, khi), nxt);
                     f32x4 dst[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int kt = ka + u;
                         f32x4 dsv = {0.f, 0.f, 0.f, 0.f};
                         if (kt <= khi) {
-                            const __bf16* e = ds_head + ((long)(qt - kt + grp.cmax) * NT + kt) * 256 + tr_off;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) dsv[r] = (float)e[4 * r];
+                            for (int r = 0; r < 4; ++r) dsv[r] = (float)cur[u][r];
                             if (BIAS) {   // dQ^T[d][ii] += sum_t Pk^T[d][t] Sx[t][ii]
                                 const int rel = qi0 - 16 * kt - 16 * c_lo;
                                 *reinterpret_cast<bf16x4*>(dsc + li * DSX_LD + 16 + 4 * g) =
@@ -582,6 +596,10 @@ __global__ __launch_bounds__(BAND_THREADS) void attn_bwd_band_kernel(const BandP
                         col_frag(a, Ks, ASTR, 16 * ka + 4 * g, 16 * ka + 16 + 4 * g, 16 * dt, lane);
                         dqacc[s][dt] = mma(a, bs, dqacc[s][dt]);
                     }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cur[u][r] = nxt[u][r];
                 }
             }
         }
