@@ -144,8 +144,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--bucket-mb', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=4)
-    ap.add_argument('--cpu-steps', type=int, default=1)
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-layers', type=int, default=24)
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--graph', action='store_true',
