@@ -98,18 +98,16 @@ def test_mha_performer_vs_reference_golden(kernel, dtype):
     assert not bad, bad
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
-@pytest.mark.parametrize('kernel,m,L', [('softmax', 256, 577), ('softmax', 64, 577), ('relu', 48, 100)])
-def test_favor_large_vs_oracle(kernel, m, L, dtype):
-    """Config-5 shape (577 tokens, dh 64), m = 256 / 64, and a ragged m: kernel vs the CPU oracle."""
+def _favor_vs_oracle(kernel, B, L, H, dh, m, dtype):
     from vit_amd import functional as VF
-    B, H, dh = 2, 3, 64
     D = H * dh
     torch.manual_seed(5)
     qkv = (torch.randn(B * L, 3 * D) * 0.5)
     w = R.gaussian_orthogonal_random_matrix(m, dh, generator=torch.Generator().manual_seed(1))
     gout = torch.randn(B * L, D)
     ratio = m ** -0.25
+    if dtype == torch.bfloat16:      # the oracle sees what the kernel sees: a rounded input that crosses a ReLU gate or
+        qkv, w = qkv.bfloat16().float(), w.bfloat16().float()      # moves the arg-max is not the kernel's error
     # oracle
     qr = qkv.clone().requires_grad_(True)
     q, k, v = (qr[:, i * D:(i + 1) * D].view(B, L, H, dh) for i in range(3))
@@ -124,6 +122,24 @@ def test_favor_large_vs_oracle(kernel, m, L, dtype):
     (out.float() * gout.cuda()).sum().backward()
     assert ok(out.detach().float().cpu(), ref.detach(), dtype, 2), (relerr(out.detach().float().cpu(), ref.detach()))
     assert ok(xg.grad.float().cpu(), qr.grad, dtype, 2), (relerr(xg.grad.float().cpu(), qr.grad), l2err(xg.grad.float().cpu(), qr.grad))
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+@pytest.mark.parametrize('kernel,m,L', [('softmax', 256, 577), ('softmax', 64, 577), ('relu', 48, 100)])
+def test_favor_large_vs_oracle(kernel, m, L, dtype):
+    """Config-5 shape (577 tokens, dh 64), m = 256 / 64, and a ragged m: kernel vs the CPU oracle."""
+    _favor_vs_oracle(kernel, 2, L, 3, 64, m, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+@pytest.mark.parametrize('kernel', ['softmax', 'relu'])
+@pytest.mark.parametrize('B,L,H,dh,m', [(1, 5, 3, 24, 10), (3, 33, 1, 8, 16), (1, 130, 5, 40, 17), (2, 64, 2, 64, 64),
+                                        (1, 1, 1, 16, 1), (5, 129, 3, 32, 33), (2, 70, 7, 56, 7)])
+def test_favor_edge_shapes_vs_oracle(kernel, B, L, H, dh, m, dtype):
+    """The LDS-staged kernels (csrc/favor_fast.hip: m <= 64) at their edges: fewer tokens than a wave's block, a single
+    token, (b, h) counts that are no multiple of the XCD count, ragged feature counts on both pitches (m = 1, 7, 10 on
+    16; 17, 33 on 64), heads of 8 ... 64 with a half-filled last K block (24, 40, 56)."""
+    _favor_vs_oracle(kernel, B, L, H, dh, m, dtype)
 
 
 DISPERF_SHAPES = (('a', 2, 65, 128, 4, 16), ('b', 2, 145, 256, 4, 64), ('c', 3, 50, 96, 2, 40))
