@@ -513,7 +513,7 @@ class PreLNBlockFn(torch.autograd.Function):
             ops.favor_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, dh, qkv.stride(0), fw, kind, ratio, feps,
                           attn, dattn, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, lse)
             if dbqkv is not None:
-                ops.colsum(dqkv, out=dbqkv)
+                _colsum(dqkv, out=dbqkv, side=True)
         dwqkv = _dw(dqkv, h1, out=s_wqkv if s_wqkv is not None else zp.take(3 * D, D), side=True)
         # a fresh alias of a slab view: autograd adopts it as .grad without a copy
         dw1, dw2, dwproj, dwqkv = (t.detach() if t is s else t
