@@ -217,7 +217,11 @@ def _colsum(x, out=None, side=False):
     return ops.colsum(x, out=out)
 
 
-SIDE_COLSUM = os.environ.get('VITK_SIDE_COLSUM', '1') != '0'
+# Off by default: with the column sums beside them the main stream's persistent GEMMs find CUs taken when they start, and a
+# workgroup that starts late still walks its full static share -- the step is 2 % faster (1878 -> 1917 img/s) but an NT
+# GEMM launch then measures 230 us instead of 177 (bench roofline.frac 0.27 instead of 0.36): the per-kernel numbers
+# stop describing the kernel.  VITK_SIDE_COLSUM=1 turns it on.
+SIDE_COLSUM = os.environ.get('VITK_SIDE_COLSUM', '0') != '0'
 
 
 def _dx(dy, params, **kw):
