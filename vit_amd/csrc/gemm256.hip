@@ -467,8 +467,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // write path (128 KiB per CU take 4.6 k cycles, against 1.9 k for a CU storing alone: tools/micro/store_rate.hip)
     // and each CU's next loads queue behind its own stores.  Workgroups that walk one item FEWER than the busiest
     // ones have a whole tile time of slack: the later quarters of each XCD's workgroups (blockIdx >> 3 >= 8), as far as
-    // it has that slack, starts late -- in `groups` phases spread over 75 % of a tile time -- so that only a fraction of
+    // it has that slack, starts late -- in `groups` phases spread over `pct` % of a tile time -- so that only a fraction of
     // an XCD stores at any time.  Same-box A/B on the layer's NT GEMMs: -2.9 % (dX fc2 -6 %, dX qkv -4 %, fc2 -3 %).
+    // That was the GEMMs alone, with 75 %.  In the training step the waiting workgroups hold CUs the second stream's dW
+    // GEMMs could use: same-box sweep of the headline step, 0 / 25 / 50 / 75 %: 1898 / 1907 / 1889 / 1872 img/s, NT launch
+    // 184 / 179 / 179 / 178 us -- the default is 25 %.
     if (p.stagger > 0) {
         const int rem = nitems % (int)gridDim.x;           // workgroups below `rem` walk one item more
         const int groups = p.stagger >> 24, ticks = p.stagger & 0xffffff;      // phase g of `groups` starts g * ticks late
@@ -734,7 +737,7 @@ void gemm256_launch(const GemmParams& p0, int c_dtype, int transA, int transB, h
     static int pct = -1, groups = 4;       // VITK_GEMM_STAGGER = total spread in % of a tile time (0: off), _GROUPS = phases
     if (pct < 0) {
         const char* e = getenv("VITK_GEMM_STAGGER");
-        pct = e ? atoi(e) : 75;
+        pct = e ? atoi(e) : 25;
         const char* g = getenv("VITK_GEMM_STAGGER_GROUPS");
         groups = g ? atoi(g) : 4;
         if (groups < 2 || groups > 32) groups = 4;
