@@ -153,6 +153,11 @@ def main():
                     help='HIP events around the kernels on every K-th step of the timed region (1 = every step)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the step as one captured HIP graph, gradient exchange included (vit_amd.graph; the per-GEMM timer is off)')
+    ap.add_argument('--max-overlap', action='store_true',
+                    help='throughput mode: two K splits instead of 16 / 4 in the proj / fc1 / fc2 weight-gradient GEMMs '
+                         '(= VITK_DW_SPLITK=16:2,64:2): they then hold 32 / 128 CUs instead of all 256 and run BESIDE the main '
+                         'stream: +2.7 %% images/s on the headline, but the main stream\'s GEMM launches share CUs with them '
+                         'and their per-launch times (roofline.frac) no longer describe the kernel')
     ap.add_argument('--force-reducer', action='store_true',
                     help='diagnostic: run the gradient reducer (flat slabs, hooks, all-reduce) even at world size 1')
     args = ap.parse_args()
@@ -161,6 +166,9 @@ def main():
     from vit_amd import ops
     from vit_amd.train import PRESETS, build_model, train_step, takes_epoch
 
+    if args.max_overlap:
+        from vit_amd import functional as VF
+        VF._DW_SPLITK = '16:2,64:2'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -334,7 +342,7 @@ def main():
                                    f'{p["mlp"]} x {p["heads"]}h), {img}x{img}/{patch}, {N} tokens, LAI w={w}, '
                                    f'dropout 0, AdamW lr 1e-4, label smoothing 0.1',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'hip_graph': bool(use_graph),
+                       'hip_graph': bool(use_graph), 'max_overlap': bool(args.max_overlap),
                        'grad_bucket_mb': args.bucket_mb if world > 1 else None},
             'train_gflop_per_image': fl_img / 1e9, 'model_tflops_per_gpu': model_tflops_gpu,
             'mfma_roofline_frac_per_gpu': model_tflops_gpu / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16

@@ -180,6 +180,28 @@ def side_join(device):
         keep.clear()
 
 
+# "tiles:splitk,..." overrides the library's split-K choice (256 / tiles: every CU busy) for the weight-gradient GEMMs with
+# that many 256 x 256 output tiles.  With FEWER splits a dW GEMM holds fewer CUs for longer and runs beside the main
+# stream instead of in turns with it, and it issues fewer split-K atomics: headline step, same box, '16:2,64:2' (proj:
+# 2 splits instead of 16; fc1 / fc2: 2 instead of 4) 1984-1990 img/s against 1930-1938, '16:4,64:3' 1976-1982, '64:3' 1959-1969;
+# more splits, or any change to the qkv one (48 tiles, 5 splits), lose 1-4 %.  Not the default for the same reason as
+# SIDE_COLSUM below: the main stream's persistent GEMMs then start with CUs taken, an NT launch measures 203 us
+# instead of 175 and bench.py's roofline.frac reads 0.31 instead of 0.36 although no kernel changed.
+# `bench.py --max-overlap` sets '16:2,64:2'.
+_DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '')
+
+
+def _dw_splitk(dy, x):
+    if not _DW_SPLITK:
+        return 0
+    tiles = ((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256)
+    for item in _DW_SPLITK.split(','):
+        t, k = item.split(':')
+        if int(t) == tiles:
+            return int(k)
+    return 0
+
+
 def _dw(dy, x, out=None, side=False):
     """dW[out, in] = dy^T x in fp32 (split-K over the token dimension).  ``out``: a ZEROED fp32 buffer to
     add into (a slice of the block's one zero-filled pool: the split-K atomics then need no memset of
@@ -193,10 +215,10 @@ def _dw(dy, x, out=None, side=False):
             ev.record()                       # dy, x and the zero fill of ``out`` are queued before this point
             st.wait_event(ev)
             with torch.cuda.stream(st):
-                ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True)
+                ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True, splitk=_dw_splitk(dy, x))
             _side_pending.setdefault(dev, []).append((dy, x, out))
             return out
-        return ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True)
+        return ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True, splitk=_dw_splitk(dy, x))
     return ops.gemm(dy, x, trans_a=True, trans_b=False, out_dtype=torch.float32)
 
 
