@@ -10,7 +10,14 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+# Opt-in (VITK_RUN_WORLD2_ON_ONE_GPU=1).  The test passes when it runs through, but the same exchange -- two processes on
+# ONE GPU, gloo staging CUDA buckets through pinned host memory on its own streams and worker threads -- hung in
+# work.wait() on both ranks in 6 of 9 longer runs (bench.py's loop and a five-step variant, steps 3-5; per-step host
+# syncs, barriers and the kernel timer make no difference; cause not established).  RCCL with one device per rank does
+# not take that path, and a hang here would hide every test collected after it under `pytest -x`.
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('VITK_RUN_WORLD2_ON_ONE_GPU') != '1',
+                                 reason='opt-in: two gloo ranks on one GPU hang intermittently (see the comment above)')]
 
 KW = dict(img_size=32, patch_size=4, num_classes=10, dtype=torch.bfloat16, depth=2)
 STEPS = 3
