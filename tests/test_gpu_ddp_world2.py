@@ -13,8 +13,10 @@ import torch.multiprocessing as mp
 # Opt-in (VITK_RUN_WORLD2_ON_ONE_GPU=1).  The test passes when it runs through, but the same exchange -- two processes on
 # ONE GPU, gloo staging CUDA buckets through pinned host memory on its own streams and worker threads -- hung in
 # work.wait() on both ranks in 6 of 9 longer runs (bench.py's loop and a five-step variant, steps 3-5; per-step host
-# syncs, barriers and the kernel timer make no difference; cause not established).  RCCL with one device per rank does
-# not take that path, and a hang here would hide every test collected after it under `pytest -x`.
+# syncs, barriers, the second stream, the optimizer and the kernel timer make no difference).  A control without any
+# vit_amd code (tools/gloo_one_gpu_control.py: torch matmuls around an async gloo all_reduce of a CUDA tensor) hangs the
+# same way, 5 runs of 5: it is gloo's CUDA staging with two processes on one device, not the reducer.  RCCL with one
+# device per rank does not take that path, and a hang here would hide every test collected after it under `pytest -x`.
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get('VITK_RUN_WORLD2_ON_ONE_GPU') != '1',
                                  reason='opt-in: two gloo ranks on one GPU hang intermittently (see the comment above)')]
