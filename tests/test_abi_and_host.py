@@ -138,3 +138,23 @@ def test_gemm_async_epilogue_loads_are_never_spilled(tmp_path):
     subprocess.run([hipcc, *_build.FLAGS, '--cuda-device-only', '-S', src, '-o', str(asm)], check=True, capture_output=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_async_loads.py'), str(asm)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_dw_splitk_override_parses_tiles():
+    """VITK_DW_SPLITK / bench.py --max-overlap: 'tiles:splitk,...' keyed on the number of 256 x 256 output tiles of the
+    weight-gradient GEMM dW[out, in] = dy^T x; anything not listed keeps the library's choice (0)."""
+    import torch
+    from vit_amd import functional as VF
+    old = VF._DW_SPLITK
+    try:
+        VF._DW_SPLITK = '16:2,64:2'
+        rows = 8
+        assert VF._dw_splitk(torch.empty(rows, 1024), torch.empty(rows, 1024)) == 2      # proj: 4 x 4 tiles
+        assert VF._dw_splitk(torch.empty(rows, 4096), torch.empty(rows, 1024)) == 2      # fc1: 16 x 4
+        assert VF._dw_splitk(torch.empty(rows, 1024), torch.empty(rows, 4096)) == 2      # fc2: 4 x 16
+        assert VF._dw_splitk(torch.empty(rows, 3072), torch.empty(rows, 1024)) == 0      # qkv: 48 tiles, not listed
+        assert VF._dw_splitk(torch.empty(rows, 1000), torch.empty(rows, 1025)) == 0      # 4 x 5 = 20 (ragged edges round up)
+        VF._DW_SPLITK = ''
+        assert VF._dw_splitk(torch.empty(rows, 1024), torch.empty(rows, 1024)) == 0
+    finally:
+        VF._DW_SPLITK = old
