@@ -255,3 +255,21 @@ def test_gemm256_persistent_items(ta, tb, M, N, K):
         y = ops.gemm(a, b, trans_b=tb, act=ops.ACT_DRELU, aux_in=gate)
         want = torch.where(gate.float() > 0, ref, torch.zeros_like(ref))
         assert (y.float() - want).abs().max().item() < 0.25 and relerr(y, want) < 1.5e-2
+
+
+@pytest.mark.parametrize('splitk', [2, 4, 16])
+def test_dw_gemm_explicit_splitk(splitk):
+    """The weight-gradient GEMM with the K splits chosen by the caller (VITK_DW_SPLITK / bench.py --max-overlap) instead
+    of the library: same sum whatever the split, accumulated into a zeroed fp32 buffer as the fused blocks do."""
+    ops = _ops()
+    torch.manual_seed(splitk)
+    rows = 25216                                   # the headline's token rows (128 x 197): proj dW, 4 x 4 tiles
+    dy = (torch.randn(rows, 1024, device='cuda') * 0.1).bfloat16()
+    x = torch.randn(rows, 1024, device='cuda').bfloat16()
+    ref = dy.float().t() @ x.float()
+    out = torch.zeros(1024, 1024, device='cuda')
+    ops.gemm(dy, x, trans_a=True, trans_b=False, out=out, accumulate=True, splitk=splitk)
+    assert relerr(out, ref) < 1e-5
+    auto = torch.zeros(1024, 1024, device='cuda')
+    ops.gemm(dy, x, trans_a=True, trans_b=False, out=auto, accumulate=True)
+    assert relerr(out, auto) < 1e-5
