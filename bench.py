@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: synthetic-image TRAINING throughput of the ViT encoder hot path.
 
-  python bench.py --gpus N --steps K --warmup W         (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W         (any N: with no WORLD_SIZE in the environment and N > 1 the
+                                                         script starts N ranks of itself, vit_amd/launch.py)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (runs as that rank)
 
 One step = forward + label-smoothing CE + backward (+ bucketed RCCL gradient all-reduce when
 N > 1, overlapped with backward) + AdamW, on one per-GPU batch of synthetic images
@@ -16,7 +17,10 @@ Extra objects on the line:
                  events around all ~600 launches of every step cost 2.4 % of the step), vs 2.5 PF.  On the
                  FAVOR+ workloads: the FAVOR+ kernels, algorithmic bytes vs 8 TB/s (bound "hbm").
                  traffic = PMC bytes per launch from profiles/ (null when that file was measured on
-                 other kernel sources).
+                 other kernel sources).  In the step the weight-gradient GEMMs run BESIDE the others on a
+                 second stream, so those in-step launch times include shared CUs (the schedule, not the
+                 kernel); roofline.isolated is the same kernel on the step's own shapes and epilogues,
+                 each timed ALONE (8 launches, HIP events) after the timed region: the kernel's quality.
   timed_kernels: the same line for every timed launch group (GEMM layouts, attention, FAVOR+).
   cpu_baseline : the CPU oracle (oracle/ref_cpu.py, the reference's algorithm in plain fp32
                  PyTorch) timed on this box's host cores on a bounded sample of the same workload.
@@ -73,12 +77,74 @@ def train_flops_per_image(variant, p, N, P, C, B, w):
     return 3.0 * fwd
 
 
+def launch_plan(gpus, env):
+    """'spawn': start `gpus` ranks of this script (vit_amd/launch.py); 'run': this process is the job (N = 1) or one
+    rank of it.  Decided from the environment alone, before anything touches the GPU."""
+    have = all(k in env for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'))
+    if not have:
+        return 'spawn' if gpus > 1 else 'run'
+    if int(env['WORLD_SIZE']) != gpus:
+        raise SystemExit(f'--gpus {gpus} but WORLD_SIZE={env["WORLD_SIZE"]}: pass the same N to the launcher and to --gpus')
+    return 'run'
+
+
+def isolated_gemms(M, D, F, dev, reps=8):
+    """The step's GEMM shapes with the step's epilogues, each timed ALONE on an idle GPU (2 warm-up + `reps` launches
+    between one pair of HIP events on the launch stream).  Kernel quality, free of the step's schedule: in the step the
+    weight-gradient GEMMs share the CUs with the forward / dX ones on purpose.  M = rows of the token matrix."""
+    from vit_amd import ops
+    bf = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(7)
+
+    def rnd(*shape, dtype=bf):
+        return (torch.randn(*shape, device=dev, generator=g, dtype=torch.float32) * 0.05).to(dtype)
+
+    xD, xF, x3 = rnd(M, D), rnd(M, F), rnd(M, 3 * D)
+    w3, wDD, wFD, wDF, wq = rnd(3 * D, D), rnd(D, D), rnd(F, D), rnd(D, F), rnd(D, 3 * D)
+    b3, bD, bF = rnd(3 * D, dtype=torch.float32), rnd(D, dtype=torch.float32), rnd(F, dtype=torch.float32)
+    oD, oF, o3, pre = torch.empty_like(xD), torch.empty_like(xF), torch.empty_like(x3), torch.empty_like(xF)
+    gDD, gFD, gDF, g3D = (torch.zeros(s, device=dev, dtype=torch.float32) for s in ((D, D), (F, D), (D, F), (3 * D, D)))
+    A = ops
+    cases = [   # (name, kernel group, flops, launch)
+        ('qkv fwd (bias)', 'gemm_NT_bf16', 2.0 * M * 3 * D * D, lambda: A.gemm(xD, w3, bias=b3, out=o3)),
+        ('proj fwd (bias + residual)', 'gemm_NT_bf16', 2.0 * M * D * D, lambda: A.gemm(xD, wDD, bias=bD, residual=xD, out=oD)),
+        ('fc1 fwd (bias + GELU + pre-activation copy)', 'gemm_NT_bf16', 2.0 * M * F * D,
+         lambda: A.gemm(xD, wFD, bias=bF, act=A.ACT_GELU, aux_out=pre, out=oF)),
+        ('fc2 fwd (bias + residual)', 'gemm_NT_bf16', 2.0 * M * D * F, lambda: A.gemm(xF, wDF, bias=bD, residual=xD, out=oD)),
+        ('fc2 dX (dGELU)', 'gemm_NT_bf16', 2.0 * M * F * D, lambda: A.gemm(xD, wFD, act=A.ACT_DGELU, aux_in=pre, out=oF)),
+        ('fc1 dX (residual)', 'gemm_NT_bf16', 2.0 * M * D * F, lambda: A.gemm(xF, wDF, residual=xD, out=oD)),
+        ('proj dX', 'gemm_NT_bf16', 2.0 * M * D * D, lambda: A.gemm(xD, wDD, out=oD)),
+        ('qkv dX (residual)', 'gemm_NT_bf16', 2.0 * M * D * 3 * D, lambda: A.gemm(x3, wq, residual=xD, out=oD)),
+        ('fc2 dW', 'gemm_TN_bf16', 2.0 * M * D * F, lambda: A.gemm(xD, xF, trans_a=True, trans_b=False, out=gDF, accumulate=True)),
+        ('fc1 dW', 'gemm_TN_bf16', 2.0 * M * D * F, lambda: A.gemm(xF, xD, trans_a=True, trans_b=False, out=gFD, accumulate=True)),
+        ('proj dW', 'gemm_TN_bf16', 2.0 * M * D * D, lambda: A.gemm(xD, xD, trans_a=True, trans_b=False, out=gDD, accumulate=True)),
+        ('qkv dW', 'gemm_TN_bf16', 2.0 * M * D * 3 * D, lambda: A.gemm(x3, xD, trans_a=True, trans_b=False, out=g3D, accumulate=True)),
+    ]
+    rows, agg = [], {}
+    for name, group, flops, fn in cases:
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        rows.append({'gemm': name, 'kernel': group, 'us': 1e6 * sec, 'tflops': flops / sec / 1e12})
+        a = agg.setdefault(group, [0.0, 0.0])
+        a[0] += flops
+        a[1] += sec
+    return rows, {k: v[0] / v[1] / 1e12 for k, v in agg.items()}
+
+
 def cpu_baseline(args, variant, preset, img, patch, classes, w):
     """Oracle (port of the reference algorithm) on host cores, bounded sample."""
     from oracle import ref_cpu as R
     from vit_amd.train import PRESETS
     p = PRESETS[preset]
-    cores = min(16, os.cpu_count() or 1)
+    host_cpus = os.cpu_count() or 1
+    cores = min(16, host_cpus)      # the GPU box gives one job 16 CPUs (OMP_NUM_THREADS there); os.cpu_count() is the whole machine
     torch.set_num_threads(cores)
     me = MASK_EPOCHS if 'lai' in variant else None
     depth = min(p['depth'], args.cpu_layers)
@@ -129,7 +195,7 @@ def cpu_baseline(args, variant, preset, img, patch, classes, w):
     # the sample runs `depth` of the model's layers; scale the per-image time to the full depth
     # with the measured per-layer cost (layers are identical; embed/head are < 1 % of the step)
     scale = p['depth'] / depth
-    return {'value': Bc / (dt * scale), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    return {'value': Bc / (dt * scale), 'unit': 'images/sec', 'cores': cores, 'host_cpus': host_cpus, 'kind': 'port',
             'sample': f'oracle/ref_cpu.py fp32, batch {Bc}, {depth} of {p["depth"]} layers timed over {n} step(s) '
                       f'(fwd+bwd+AdamW), per-image time scaled x{scale:g} to full depth'}
 
@@ -153,27 +219,46 @@ def main():
                     help='HIP events around the kernels on every K-th step of the timed region (1 = every step)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the step as one captured HIP graph, gradient exchange included (vit_amd.graph; the per-GEMM timer is off)')
-    ap.add_argument('--max-overlap', action='store_true',
-                    help='throughput mode: two K splits instead of 16 / 4 in the proj / fc1 / fc2 weight-gradient GEMMs '
-                         '(= VITK_DW_SPLITK=16:2,64:2): they then hold 32 / 128 CUs instead of all 256 and run BESIDE the main '
-                         'stream: +2.7 %% images/s on the headline, but the main stream\'s GEMM launches share CUs with them '
-                         'and their per-launch times (roofline.frac) no longer describe the kernel')
+    ap.add_argument('--no-max-overlap', action='store_true',
+                    help='the library\'s own K splits (256 / tiles: 16 / 4 / 4) in the proj / fc1 / fc2 weight-gradient GEMMs and the '
+                         'bias-gradient column sums on the main stream, instead of the default throughput schedule (two K splits = '
+                         'VITK_DW_SPLITK=16:2,64:2, the dW GEMMs holding 32 / 128 CUs BESIDE the main stream, column sums on the side '
+                         'stream: +3-4 %% images/s on the headline).  With this flag the in-step launch times describe each kernel '
+                         'alone again (round 2\'s default); roofline.isolated measures that directly either way')
+    ap.add_argument('--dropout', type=float, default=0.0,
+                    help='dropout probability at every nn.Dropout site of the model (reference default: 0.1, train.py:79)')
+    ap.add_argument('--comm-dtype', default='f32', choices=['f32', 'bf16'],
+                    help='what the gradient buckets travel as (N > 1): f32 = the reference\'s DDP, bf16 = half the bytes')
+    ap.add_argument('--reserve-cus', type=int, default=-1,
+                    help='CUs the persistent GEMM launches leave free for RCCL\'s kernels (-1: 0 at N = 1, 16 at N > 1)')
+    ap.add_argument('--no-isolated', action='store_true', help='skip the isolated per-shape GEMM pass after the timed region')
     ap.add_argument('--force-reducer', action='store_true',
                     help='diagnostic: run the gradient reducer (flat slabs, hooks, all-reduce) even at world size 1')
     args = ap.parse_args()
+
+    # One process per GPU.  Started plain with --gpus N > 1: start N ranks of this very command line as CHILD processes
+    # (before any GPU call; nothing is exec'ed), rank 0 prints the JSON line on our stdout.
+    if launch_plan(args.gpus, os.environ) == 'spawn':
+        from vit_amd.launch import spawn_ranks
+        raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]))
 
     import torch.distributed as dist
     from vit_amd import ops
     from vit_amd.train import PRESETS, build_model, train_step, takes_epoch
 
-    if args.max_overlap:
-        from vit_amd import functional as VF
-        VF._DW_SPLITK = '16:2,64:2'
+    from vit_amd import functional as VF
+    max_overlap = not args.no_max_overlap
+    if not max_overlap:
+        VF._DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '')
+        VF.SIDE_COLSUM = os.environ.get('VITK_SIDE_COLSUM', '0') != '0'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (16 if world > 1 else 0)
+    ops.set_reserved_cus(reserve)
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f'rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible): '
+                         f'--gpus {args.gpus} needs {args.gpus} devices on this node (one process per GPU over RCCL)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1 or args.force_reducer:
@@ -193,14 +278,19 @@ def main():
 
     torch.manual_seed(0)       # identical init on every rank (rank 0 is broadcast anyway)
     net = build_model(variant, preset, img_size=img, patch_size=patch, num_classes=classes,
-                      mask_epochs=MASK_EPOCHS if 'lai' in variant else None, dtype=dtype, device=dev)
+                      mask_epochs=MASK_EPOCHS if 'lai' in variant else None, dtype=dtype, device=dev, dropout=args.dropout)
+    if args.dropout > 0:
+        from vit_amd import dropout as VD
+        VD.manual_seed(4321 + rank)
+        net.train()
     from vit_amd.optim import AdamW
     use_graph = args.graph          # with a reducer the RCCL exchange is captured too (vit_amd.graph)
     opt = AdamW(net.parameters(), lr=1e-4, capturable=use_graph)
     reducer = None
     if world > 1 or args.force_reducer:
         from vit_amd.ddp import GradReducer
-        reducer = GradReducer(net, bucket_mb=args.bucket_mb)
+        reducer = GradReducer(net, bucket_mb=args.bucket_mb, always_reduce=args.force_reducer,
+                              comm_dtype=torch.bfloat16 if args.comm_dtype == 'bf16' else torch.float32)
     epoch = STAGE_EPOCH[args.band] if takes_epoch(net) else None
     w = args.band if ('lai' in variant and epoch is not None) else -1
 
@@ -327,6 +417,24 @@ def main():
             roofline['overlap_note'] = ('dW GEMMs (gemm_TN) run on a second stream beside the dX GEMMs: per-launch durations include '
                                         'the time they share CUs; all_gemm_* are over the union of the launch spans')
         kernels = [line(k) for k in sorted(agg, key=lambda k: -agg[k][1])]
+        if max_overlap and gemms:
+            roofline['schedule_note'] = ('default schedule: the dW GEMMs hold 32 / 128 CUs beside the main stream, so in-step launch '
+                                         'times of the NT GEMMs include shared CUs; roofline.isolated = the same kernel alone')
+
+    # Kernel quality apart from the schedule: every GEMM shape of one encoder layer, with its epilogue, timed alone.
+    if roofline is not None and rank == 0 and dtype == torch.bfloat16 and not args.no_isolated and roofline['bound'] == 'mfma':
+        rows_tok = B * N
+        if variant in ('disentangled_attention', 'disentangled_lai_attention'):
+            rows_tok += VF._tail_rows(rows_tok, 2 * N - 1)      # the relative-table rows ride along (functional.DisLayerFn)
+        torch.cuda.synchronize()
+        per_shape, by_kernel = isolated_gemms(rows_tok, p['dim'], p['mlp'], dev)
+        iso = by_kernel.get(roofline['kernel'])
+        roofline['isolated'] = {
+            'what': f'each GEMM of one encoder layer ([{rows_tok}, {p["dim"]}] tokens, MLP {p["mlp"]}) with its fused epilogue, alone on the '
+                    'GPU: 2 warm-up + 8 launches between one pair of HIP events, after the timed region',
+            'kernel': roofline['kernel'], 'achieved': iso, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': None if iso is None else iso / PEAK_BF16_TFLOPS,
+            'by_kernel_tflops': by_kernel, 'per_shape': per_shape}
 
     if rank == 0:
         cpu = None
@@ -340,10 +448,11 @@ def main():
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {variant} preset {preset} ({p["depth"]}L x {p["dim"]} x '
                                    f'{p["mlp"]} x {p["heads"]}h), {img}x{img}/{patch}, {N} tokens, LAI w={w}, '
-                                   f'dropout 0, AdamW lr 1e-4, label smoothing 0.1',
+                                   f'dropout {args.dropout:g}, AdamW lr 1e-4, label smoothing 0.1',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'hip_graph': bool(use_graph), 'max_overlap': bool(args.max_overlap),
-                       'grad_bucket_mb': args.bucket_mb if world > 1 else None},
+                       'hip_graph': bool(use_graph), 'max_overlap': bool(max_overlap), 'reserved_cus': reserve,
+                       'grad_bucket_mb': args.bucket_mb if reducer is not None else None,
+                       'grad_comm_dtype': args.comm_dtype if reducer is not None else None},
             'train_gflop_per_image': fl_img / 1e9, 'model_tflops_per_gpu': model_tflops_gpu,
             'mfma_roofline_frac_per_gpu': model_tflops_gpu / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16
                                                                 else PEAK_F32_TFLOPS),

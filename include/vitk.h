@@ -30,8 +30,18 @@ extern "C" {
 #define VITK_ACT_DGELU 3  /* out = (A.B) * gelu'(aux_in),  aux_in = saved pre-activation */
 #define VITK_ACT_DRELU 4  /* out = (A.B) * (aux_in > 0),   aux_in = saved activation output */
 
+/* ABI version: bumped whenever an entry point's argument list changes; vitk_version() of the loaded library must
+ * equal the VITK_ABI_VERSION the caller was compiled / written against (vit_amd/_lib.py checks exactly that). */
+#define VITK_ABI_VERSION 3
 int vitk_version(void);
 const char* vitk_last_error(void);
+
+/* CUs that the persistent GEMM launches (one workgroup per CU holding its whole LDS) leave free, 0..128, process-wide.
+ * For the data-parallel step: DDP's NCCL kernels share the GPU with backward (train.py:635, utils/ops.py:124-133);
+ * RCCL's reduction kernels need CUs that a 160 KiB-LDS workgroup would otherwise hold until it exits.  Default 0, or
+ * the environment's VITK_RESERVED_CUS.  The grid stays a multiple of 8 (XCD mapping). */
+int vitk_set_reserved_cus(int n);
+int vitk_get_reserved_cus(void);
 
 /* Zero fills under HIP graph capture.  Entry points that accumulate with atomics (vitk_gemm with split-K or
  * accumulate, vitk_attn_bwd's table gradients, vitk_colsum, the FAVOR+ state) need their targets zeroed first; where the

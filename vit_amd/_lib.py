@@ -8,6 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VITK_LIB') or os.path.join(HERE, 'lib', 'libvitk.so')   # VITK_LIB: an instrumented build (tools/)
 
+ABI_VERSION = 3        # include/vitk.h VITK_ABI_VERSION: the argument lists below are those of exactly this version
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
 
@@ -19,6 +20,8 @@ c_u64 = ctypes.c_ulonglong
 _SIGNATURES = {
     'vitk_version': ([], c_int),
     'vitk_last_error': ([], ctypes.c_char_p),
+    'vitk_set_reserved_cus': ([c_int], c_int),
+    'vitk_get_reserved_cus': ([], c_int),
     'vitk_gemm': ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                    c_vp, c_long, c_vp, c_long, c_vp, c_long,
                    c_vp, c_int, c_vp, c_vp, c_long,
@@ -93,6 +96,10 @@ def lib():
                 continue
             fn = getattr(L, name)
             fn.argtypes, fn.restype = sig
+        have = L.vitk_version() if hasattr(L, 'vitk_version') else None
+        if have != ABI_VERSION:
+            raise VitkError(f'{LIB_PATH} has ABI version {have}, this binding is written for {ABI_VERSION}: rebuild it '
+                            '(`python -m vit_amd._build`); a stale library would misalign arguments silently')
         _lib = L
     return _lib
 

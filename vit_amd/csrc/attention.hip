@@ -182,12 +182,7 @@ template <typename T, int DKB, int KT, bool BIAS> static size_t attn_fwd_lds() {
 template <typename T, int DKB, int KT, bool BIAS>
 static void attn_fwd_launch(const AttnFwdParams& p, hipStream_t st) {
     const size_t lds = attn_fwd_lds<T, DKB, KT, BIAS>();
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, DKB, KT, BIAS>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    (void)vitk_lds_optin((const void*)attn_fwd_kernel<T, DKB, KT, BIAS>, lds);
     dim3 grid((p.N + 63) / 64, p.H, p.B);
     hipLaunchKernelGGL((attn_fwd_kernel<T, DKB, KT, BIAS>), grid, dim3(256), lds, st, p);
 }

@@ -1003,30 +1003,23 @@ static_assert(2 * 224 * 72 * 2 + 2 * 96 * 72 * 2 + 2 * 224 * 4 + BAND_WAVES * (2
 static_assert(224 * 88 * 2 + 64 * 88 * 2 + 13 * BAND_DS_ELEMS * 2 + 80 * 4 <= 80 * 1024, "dQ, 80-wide head: two workgroups per CU");
 static_assert(224 * 72 * 2 + 96 * 72 * 2 + 13 * BAND_DS_ELEMS * 2 + 64 * 4 <= 80 * 1024, "dQ, 64-wide head: two workgroups per CU");
 
-template <typename Kern> static void band_set_lds(Kern kern, size_t lds, size_t& attr) {
-    if (lds > attr) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
-}
+// per (kernel, device), grows monotonically, thread-safe (runtime.hip)
+template <typename Kern> static void band_set_lds(Kern kern, size_t lds) { (void)vitk_lds_optin((const void*)kern, lds); }
 
 template <int DW, bool BIAS> static void band_fwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
     const size_t lds = BandCfg<DW, BIAS>::fwd_bytes(NT, cmax);
-    static size_t attr = 0;
-    band_set_lds(attn_fwd_band_kernel<DW, BIAS>, lds, attr);
+    band_set_lds(attn_fwd_band_kernel<DW, BIAS>, lds);
     const int chunks = (NT + BAND_CH - 1) / BAND_CH;
     hipLaunchKernelGGL((attn_fwd_band_kernel<DW, BIAS>), dim3(p.H, p.B, chunks), dim3(BAND_FWD_THREADS), lds, st, p);
 }
 template <int DW, bool BIAS> static void band_bwd_launch(const BandParams& p, int NT, int cmax, hipStream_t st) {
     const size_t lds_kv = BandCfg<DW, BIAS>::bwd_kv_bytes(NT, cmax), lds_q = BandCfg<DW, BIAS>::bwd_q_bytes(NT, cmax);
-    static size_t attr_kv = 0, attr_q = 0;
-    band_set_lds(attn_bwd_band_kv_kernel<DW, BIAS>, lds_kv, attr_kv);
-    band_set_lds(attn_bwd_band_q_kernel<DW, BIAS>, lds_q, attr_q);
+    band_set_lds(attn_bwd_band_kv_kernel<DW, BIAS>, lds_kv);
+    band_set_lds(attn_bwd_band_q_kernel<DW, BIAS>, lds_q);
     const int chunks = (NT + BAND_CH - 1) / BAND_CH;
     if (chunks == 1) {
         const size_t lds = BandCfg<DW, BIAS>::bwd_bytes(NT, cmax);
-        static size_t attr = 0;
-        band_set_lds(attn_bwd_band_kernel<DW, BIAS>, lds, attr);
+        band_set_lds(attn_bwd_band_kernel<DW, BIAS>, lds);
         hipLaunchKernelGGL((attn_bwd_band_kernel<DW, BIAS>), dim3(p.H, p.B), dim3(BAND_THREADS), lds, st, p);
         return;
     }

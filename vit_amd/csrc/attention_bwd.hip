@@ -826,24 +826,14 @@ static void bwd_launch(const AttnBwdParams& p, hipStream_t st) {
     using BC = BwdCfg<T, DKB, KTW, NW, BIAS>;
     static_assert(BC::lds_bytes() <= 160 * 1024, "attention backward tile does not fit the LDS");
     const size_t lds = BC::lds_bytes();
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, DKB, KTW, NW, BIAS>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    (void)vitk_lds_optin((const void*)attn_bwd_kernel<T, DKB, KTW, NW, BIAS>, lds);
     dim3 grid((p.N + BC::KB - 1) / BC::KB, p.H, p.B);
     hipLaunchKernelGGL((attn_bwd_kernel<T, DKB, KTW, NW, BIAS>), grid, dim3(BC::NT), lds, st, p);
 }
 
 template <typename T, int DKB> static void rel_launch(const AttnBwdParams& p, int zgroups, hipStream_t st) {
     const size_t lds = 4 * RelCfg<T, DKB>::wave_bytes();
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_rel_kernel<T, DKB>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    (void)vitk_lds_optin((const void*)attn_bwd_rel_kernel<T, DKB>, lds);
     const int NT = (p.N + 15) / 16;
     int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
     if (cmax > NT - 1) cmax = NT - 1;
@@ -854,12 +844,7 @@ template <typename T, int DKB> static void rel_launch(const AttnBwdParams& p, in
 
 template <int DKB> static void relds_launch(const AttnBwdParams& p, int zgroups, hipStream_t st) {
     const size_t lds = 4 * RelDsCfg<DKB>::wave_bytes();
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_relds_kernel<DKB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr = true;
-    }
+    (void)vitk_lds_optin((const void*)attn_bwd_relds_kernel<DKB>, lds);
     const int NT = (p.N + 15) / 16;
     int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
     if (cmax > NT - 1) cmax = NT - 1;

@@ -204,8 +204,15 @@ static inline vitk::DropParams vitk_drop_params(float p, unsigned long long seed
 // when the stream is being captured into a HIP graph.  rows x row_bytes with a row pitch (pitch == row_bytes: flat).
 extern "C" int vitk_zero_async(void* ptr, size_t pitch, size_t row_bytes, size_t rows, hipStream_t stream);
 
+// Opt a kernel in to `bytes` of dynamic LDS (> 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute
+// is PER DEVICE: it is tracked per (kernel, current device) under a mutex (forward and autograd threads both launch),
+// and a failure is kept for the VITK_CHECK_LAUNCH that follows the launch (runtime.hip).
+extern "C" int vitk_lds_optin(const void* kernel, size_t bytes);
+extern "C" int vitk_optin_failed(void);      // 1 (and cleared) when an opt-in failed on this thread since the last check
+
 #define VITK_CHECK_LAUNCH(what)                                              \
     do {                                                                     \
+        if (vitk_optin_failed()) return VITK_ERR_LAUNCH;                     \
         hipError_t e__ = hipGetLastError();                                  \
         if (e__ != hipSuccess) {                                             \
             vitk_set_error("%s: HIP error %s", what, hipGetErrorString(e__)); \

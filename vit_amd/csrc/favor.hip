@@ -781,11 +781,7 @@ template <typename T, int DKB, int MT> void launch_fwd(const FavorParams& p, hip
         hipLaunchKernelGGL((favor_kmax_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), 0, st, p);
     }
     const size_t lds = (size_t)4 * 32 * C::ASTR * sizeof(T) + (size_t)(32 * DKB * (16 * MTC + 4) + 16 * MTC) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)favor_kv_kernel<T, DKB, MTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    (void)vitk_lds_optin((const void*)favor_kv_kernel<T, DKB, MTC>, lds);
     hipLaunchKernelGGL((favor_kv_kernel<T, DKB, MTC>), dim3(MT / MTC, p.H, p.B), dim3(256), lds, st, p);
     hipLaunchKernelGGL((favor_out_kernel<T, DKB, MT>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), 0, st, p);
 }
@@ -797,12 +793,8 @@ template <typename T, int DKB, int MT> void launch_bwd(const FavorParams& p, hip
     const size_t lds_q = (size_t)(32 * DKB * (MP + 8) + 4 * 16 * C::ASTR) * sizeof(T) +
                          (size_t)(32 * DKB * (MP + 4) + MP + 4 * 64) * 4;
     const size_t lds_k = (size_t)(32 * DKB * (MP + 8)) * sizeof(T);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)favor_bwd_q_kernel<T, DKB, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        (void)hipFuncSetAttribute((const void*)favor_bwd_kv_kernel<T, DKB, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
-        attr = true;
-    }
+    (void)vitk_lds_optin((const void*)favor_bwd_q_kernel<T, DKB, MT>, lds_q);
+    (void)vitk_lds_optin((const void*)favor_bwd_kv_kernel<T, DKB, MT>, lds_k);
     hipLaunchKernelGGL((favor_bwd_q_kernel<T, DKB, MT>), dim3(p.H, p.B), dim3(256), lds_q, st, p);
     hipLaunchKernelGGL((favor_bwd_kv_kernel<T, DKB, MT>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), lds_k, st, p);
     if (p.kind == FAVOR_SOFTMAX) hipLaunchKernelGGL(favor_fix_kernel<T>, dim3(1), dim3(64), 0, st, p);

@@ -826,9 +826,7 @@ __global__ __launch_bounds__(BkvWaves<T>::NW * 64) void favor_bwd_kv_fast_kernel
 
 namespace {
 
-template <typename K> void set_lds(K kernel, size_t bytes) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
+template <typename K> void set_lds(K kernel, size_t bytes) { (void)vitk_lds_optin((const void*)kernel, bytes); }
 
 // 64-token groups per workgroup for the kernels that stage per-(b, h) state and then walk tokens: as many as still
 // leaves `want` workgroups in the launch
@@ -843,13 +841,13 @@ template <typename T, int DKB, int MT, int KIND, bool POS> void launch_fast(cons
     FavorParams p = p0;
     p.kmax_slots = KMAX_SLOTS;
     const int ng = (p.L + 63) / 64;
-    static bool attr = false;
-    if (!attr) {
+    // per (kernel, device), thread-safe (vitk_lds_optin): the opt-in is a per-device attribute
+    if (!bwd) {
         set_lds(favor_kv_fast_kernel<T, DKB, MT, MTC, KIND, POS>, F::kv_bytes(MTC));
         set_lds(favor_out_fast_kernel<T, DKB, MT, KIND, POS>, F::out_bytes);
+    } else {
         set_lds(favor_bwd_q_fast_kernel<T, DKB, MT, KIND, POS>, F::bwd_q_bytes);
         set_lds(favor_bwd_kv_fast_kernel<T, DKB, MT, KIND, POS>, F::bwd_kv_bytes);
-        attr = true;
     }
     if (!bwd) {
         if (KIND == FAVOR_SOFTMAX) {

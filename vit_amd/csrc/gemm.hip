@@ -215,12 +215,8 @@ static void launch_gemm(const GemmParams& p, int transA, int transB, hipStream_t
     const bool a_km = transA != 0, b_km = transB == 0;
 #define VITK_LAUNCH(AK, BK_)                                                                      \
     do {                                                                                          \
-        static bool attr_set = false; /* > 64 KiB of dynamic LDS needs an explicit opt-in */      \
-        if (!attr_set) {                                                                          \
-            (void)hipFuncSetAttribute((const void*)gemm_kernel<T, TC, AK, BK_>,                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-            attr_set = true;                                                                      \
-        }                                                                                         \
+        /* > 64 KiB of dynamic LDS needs an explicit opt-in, per device */                        \
+        (void)vitk_lds_optin((const void*)gemm_kernel<T, TC, AK, BK_>, lds);                      \
         hipLaunchKernelGGL((gemm_kernel<T, TC, AK, BK_>), dim3(grid), dim3(256), lds, stream, p); \
     } while (0)
     if (!a_km && !b_km) VITK_LAUNCH(false, false);

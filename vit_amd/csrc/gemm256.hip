@@ -685,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #undef VITK_VMCNT
 #undef VITK_FENCE
 
+extern "C" int vitk_get_reserved_cus(void);
 static int cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -699,19 +700,15 @@ static int cu_count() {
 
 template <typename TC> static void launch256(const GemmParams& p, int transA, int transB, hipStream_t stream) {
     const int nitems = p.tiles_m * p.tiles_n * p.splitk;
-    int grid = cu_count() & ~7;            // a multiple of 8 keeps item -> XCD fixed across rounds
+    // a multiple of 8 keeps item -> XCD fixed across rounds; vitk_set_reserved_cus() leaves CUs to other kernels (RCCL)
+    int grid = (cu_count() - vitk_get_reserved_cus()) & ~7;
     if (grid < 8) grid = 8;
     if (grid > nitems) grid = nitems;
     const size_t lds = STAGES_BYTES + EPI_BYTES;
     const bool a_km = transA != 0, b_km = transB == 0;
 #define VITK_L256(AK, BK_)                                                                           \
     do {                                                                                             \
-        static bool attr_set = false;                                                                \
-        if (!attr_set) {                                                                             \
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<TC, AK, BK_>,                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-            attr_set = true;                                                                         \
-        }                                                                                            \
+        (void)vitk_lds_optin((const void*)gemm256_kernel<TC, AK, BK_>, lds);                         \
         hipLaunchKernelGGL((gemm256_kernel<TC, AK, BK_>), dim3(grid), dim3(512), lds, stream, p);    \
     } while (0)
     if (!a_km && !b_km) VITK_L256(false, false);

@@ -1,4 +1,8 @@
 // Library-wide runtime bits of the C-ABI: version, per-thread error text.
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstring>
 #include <stdarg.h>
 #include <stdio.h>
@@ -16,7 +20,55 @@ extern "C" void vitk_set_error(const char* fmt, ...) {
 
 extern "C" const char* vitk_last_error(void) { return g_err; }
 
-extern "C" int vitk_version(void) { return 1; }
+// ---- dynamic-LDS opt-in, per (kernel, device) --------------------------------------------------------------------
+static std::mutex g_optin_mu;
+static std::map<std::pair<const void*, int>, size_t> g_optin;      // largest size already granted
+static thread_local bool g_optin_bad = false;
+
+extern "C" int vitk_lds_optin(const void* kernel, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(g_optin_mu);
+    size_t& have = g_optin[std::make_pair(kernel, dev)];
+    if (bytes <= have) return VITK_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        vitk_set_error("dynamic LDS opt-in of %zu bytes failed on device %d: %s", bytes, dev, hipGetErrorString(e));
+        g_optin_bad = true;
+        (void)hipGetLastError();
+        return VITK_ERR_LAUNCH;
+    }
+    have = bytes;
+    return VITK_OK;
+}
+extern "C" int vitk_optin_failed(void) {
+    const bool bad = g_optin_bad;
+    g_optin_bad = false;
+    return bad ? 1 : 0;
+}
+
+// Bumped whenever an entry point's argument list changes (round 2 added arguments to vitk_attn_fwd / _bwd without a bump:
+// a stale library then misaligns arguments silently).  include/vitk.h carries the same number as VITK_ABI_VERSION and
+// vit_amd/_lib.py refuses a library whose version differs from the one it was written for.
+extern "C" int vitk_version(void) { return 3; }
+
+// CUs the persistent launches (one 160 KiB-LDS workgroup per CU: gemm256) leave free -- for RCCL's reduction kernels
+// while gradient buckets are in flight (a workgroup that owns a CU's whole LDS keeps every other kernel off that CU
+// until it exits).  Process-wide; read at launch time.
+static int g_reserved_cus = -1;
+extern "C" int vitk_set_reserved_cus(int n) {
+    VITK_CHECK_ARG(n >= 0 && n <= 128, "vitk_set_reserved_cus: %d is outside [0, 128]", n);
+    g_reserved_cus = n;
+    return VITK_OK;
+}
+extern "C" int vitk_get_reserved_cus(void) {
+    if (g_reserved_cus < 0) {
+        const char* e = getenv("VITK_RESERVED_CUS");
+        int n = e ? atoi(e) : 0;
+        g_reserved_cus = n < 0 ? 0 : (n > 128 ? 128 : n);
+    }
+    return g_reserved_cus;
+}
 
 namespace vitk {
 // rows x row_bytes at a row pitch; 4-byte granularity (every caller zeroes fp32 / 8-byte counters)

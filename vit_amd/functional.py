@@ -184,11 +184,11 @@ def side_join(device):
 # that many 256 x 256 output tiles.  With FEWER splits a dW GEMM holds fewer CUs for longer and runs beside the main
 # stream instead of in turns with it, and it issues fewer split-K atomics: headline step, same box, '16:2,64:2' (proj:
 # 2 splits instead of 16; fc1 / fc2: 2 instead of 4) 1984-1990 img/s against 1930-1938, '16:4,64:3' 1976-1982, '64:3' 1959-1969;
-# more splits, or any change to the qkv one (48 tiles, 5 splits), lose 1-4 %.  Not the default for the same reason as
-# SIDE_COLSUM below: the main stream's persistent GEMMs then start with CUs taken, an NT launch measures 203 us
-# instead of 175 and bench.py's roofline.frac reads 0.31 instead of 0.36 although no kernel changed.
-# `bench.py --max-overlap` sets '16:2,64:2'.
-_DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '')
+# more splits, or any change to the qkv one (48 tiles, 5 splits), lose 1-4 %.  The default since round 3 (round 2 kept the
+# library's own splits so that the in-step launch times of the main stream's GEMMs described those kernels alone: 175 us
+# per NT launch against 203 beside the dW GEMMs; bench.py now measures kernel quality in a pass of its own,
+# roofline.isolated, and the step runs the faster schedule).  VITK_DW_SPLITK='' / `bench.py --no-max-overlap`: the old one.
+_DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '16:2,64:2')
 
 
 def _dw_splitk(dy, x):
@@ -239,11 +239,10 @@ def _colsum(x, out=None, side=False):
     return ops.colsum(x, out=out)
 
 
-# Off by default: with the column sums beside them the main stream's persistent GEMMs find CUs taken when they start, and a
-# workgroup that starts late still walks its full static share -- the step is 2 % faster (1878 -> 1917 img/s) but an NT
-# GEMM launch then measures 230 us instead of 177 (bench roofline.frac 0.27 instead of 0.36): the per-kernel numbers
-# stop describing the kernel.  VITK_SIDE_COLSUM=1 turns it on.
-SIDE_COLSUM = os.environ.get('VITK_SIDE_COLSUM', '0') != '0'
+# The bias-gradient column sums of a fused block run on the side stream too: beside a persistent GEMM on every CU the 30 us
+# pass took 180 us of the main stream's time (1878 -> 1917 img/s).  On since round 3 (see _DW_SPLITK above for why round 2
+# left it off); VITK_SIDE_COLSUM=0 / `bench.py --no-max-overlap` puts them back on the main stream.
+SIDE_COLSUM = os.environ.get('VITK_SIDE_COLSUM', '1') != '0'
 
 
 def _dx(dy, params, **kw):

@@ -30,6 +30,14 @@ def _t1(e0, name, work, unit):
         KERNEL_TIMER.append((name, float(work), e0, e1, unit))
 
 
+def set_reserved_cus(n):
+    """CUs the persistent GEMM launches leave free for other kernels (RCCL's reductions while gradient buckets are in
+    flight): vitk_set_reserved_cus.  Process-wide; returns the previous value."""
+    old = lib().vitk_get_reserved_cus()
+    check(lib().vitk_set_reserved_cus(int(n)), 'vitk_set_reserved_cus')
+    return old
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
