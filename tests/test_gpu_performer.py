@@ -22,9 +22,13 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # qkv activations are rounded to bf16 as well, and m = 16 features flip more weight per gate) get
 # 5e-2 (measured 3.1-3.9e-2 on the two worst gradients, <= 2e-2 on every output).
 TOL = {torch.float32: 1e-5, torch.bfloat16: 3e-2}
-# fp32 modules (projection GEMMs around the FAVOR+ kernels, split-K atomics in their gradients): the worst element
-# sits AT 1e-5 (1.00014e-5 seen on one run of the m = 64 softmax golden, 0.8-0.97e-5 on others): 1.5e-5 for chains.
-MODULE_SCALE = {torch.float32: 1.5, torch.bfloat16: 5.0 / 3.0}
+# fp32 modules (projection GEMMs around the FAVOR+ kernels): the same 1e-5.  Round 2 allowed 1.5e-5 because one gradient
+# element of the m = 64 softmax golden moved between 0.8e-5 and 1.0001e-5 from run to run with the order of the split-K
+# atomics of the fp32 weight-gradient GEMMs; the fp32 path no longer splits K (csrc/gemm.hip: one K-ordered chain per
+# element, bit-reproducible).  bf16 modules: 5e-2 relative L2 (the fp32 oracle on bf16-rounded inputs alone is already at
+# 1-2e-2, tests/test_favor_floor.py).  The per-tensor errors measured against these bars are written by the tests
+# themselves when VITK_REPORT_ERRORS names a file; profiles/r03_favor_parity_errors.jsonl is that file from one MI355X run.
+MODULE_SCALE = {torch.float32: 1.0, torch.bfloat16: 5.0 / 3.0}
 DTYPES = [torch.float32, torch.bfloat16]
 IDS = ['f32', 'bf16']
 
@@ -45,6 +49,18 @@ def ok(a, b, dtype, scale=1.0):
     if dtype == torch.float32:
         return relerr(a, b) < TOL[dtype] * scale
     return l2err(a, b) < TOL[dtype] * scale and relerr(a, b) < 0.2
+
+
+def report(test, dtype, errs):
+    """errs: {tensor: (max-norm error, relative L2 error)} -> one JSON line in $VITK_REPORT_ERRORS (the margin to the bars)."""
+    path = os.environ.get('VITK_REPORT_ERRORS')
+    if path:
+        import json
+        with open(path, 'a') as f:
+            f.write(json.dumps({'test': test, 'dtype': str(dtype).replace('torch.', ''),
+                                'bar': {'max_norm': TOL[dtype] * MODULE_SCALE[dtype] if dtype == torch.float32 else 0.2,
+                                        'rel_l2': None if dtype == torch.float32 else TOL[dtype] * MODULE_SCALE[dtype]},
+                                'errors': {k: {'max_norm': v[0], 'rel_l2': v[1]} for k, v in errs.items()}}) + '\n')
 
 
 def run_with_grads(fn, x, params, gout_seed):
@@ -76,6 +92,7 @@ def test_performer_attention_vs_reference_golden(m, kernel, dtype):
     set_compute_dtype(mod.cuda(), dtype)
     mod.w = torch.from_numpy(g[pre + 'w']).cuda()
     r = run_with_grads(lambda t: mod(t), x, list(mod.named_parameters()), 44)
+    report(f'performer_attention[{kernel},m{m}]', dtype, {k: (relerr(v, g[pre + k]), l2err(v, g[pre + k])) for k, v in r.items()})
     bad = [(k, relerr(v, g[pre + k]), l2err(v, g[pre + k])) for k, v in r.items() if not ok(v, g[pre + k], dtype, MODULE_SCALE[dtype])]
     assert not bad, bad
 
@@ -94,6 +111,7 @@ def test_mha_performer_vs_reference_golden(kernel, dtype):
     set_compute_dtype(mod.cuda(), dtype)
     mod.w = torch.from_numpy(g[pre + 'w']).cuda()
     r = run_with_grads(lambda t: mod(t, t, t)[0], x, list(mod.named_parameters()), 48)
+    report(f'mha_performer[{kernel}]', dtype, {k: (relerr(v, g[pre + k]), l2err(v, g[pre + k])) for k, v in r.items()})
     bad = [(k, relerr(v, g[pre + k]), l2err(v, g[pre + k])) for k, v in r.items() if not ok(v, g[pre + k], dtype, MODULE_SCALE[dtype])]
     assert not bad, bad
 

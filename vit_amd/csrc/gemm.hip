@@ -292,7 +292,10 @@ extern "C" int vitk_gemm(int dtype, int c_dtype, int transA, int transB, int M, 
     const int tiles_m = (M + tile - 1) / tile, tiles_n = (N + tile - 1) / tile;
     if (splitk <= 0) {  // auto: only when the output is fp32 and there is no nonlinear epilogue
         splitk = 1;
-        if (linear_f32) {
+        // fp32 INPUTS are the parity path (1e-5 against the reference): no split-K there, so that every output element is one
+        // K-ordered fmaf chain -- bit-reproducible run to run.  With atomics the order of the partial sums changed between
+        // runs and one gradient element of the FAVOR+ module goldens landed on either side of the bar (0.8-1.0001e-5).
+        if (linear_f32 && dtype == VITK_BF16) {
             const int tiles = tiles_m * tiles_n;
             if (big) {   // one 256-tile workgroup per CU: fill the 256 CUs once, never spill into a second round
                 splitk = 256 / tiles;

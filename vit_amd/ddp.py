@@ -27,7 +27,7 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, module, bucket_mb=128, process_group=None, broadcast=True, comm_dtype=torch.float32,
-                 always_reduce=False):
+                 always_reduce=False, reserve_cus=None):
         if not dist.is_initialized():
             raise RuntimeError('GradReducer needs torch.distributed to be initialised')
         self.group = process_group
@@ -53,6 +53,12 @@ class GradReducer:
         # exchange -- RCCL's stream, the async handles, their capture into a HIP graph -- as a run on N GPUs would do it
         self.always_reduce = bool(always_reduce)
         self._stage = {}
+        # reserve_cus: CUs the persistent GEMM launches leave free while collectives are in flight (vitk_set_reserved_cus).
+        # A gemm256 workgroup owns its CU's whole LDS until it has walked all its tiles, so on a fully taken chip RCCL's
+        # reduction kernels would wait for a GEMM to end, bucket after bucket.  None: leave the process-wide setting.
+        if reserve_cus is not None and (self.world > 1 or self.always_reduce):
+            from . import ops
+            ops.set_reserved_cus(reserve_cus)
         if broadcast and self.world > 1:
             self.broadcast_parameters(module)
 
