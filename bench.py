@@ -266,7 +266,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)
+        from vit_amd.ddp import init_process_group
+        init_process_group('nccl', device=dev)      # RCCL's stream in the high-priority class: a hardware queue of its own
 
     variant, preset, img, patch, classes, dbatch = WORKLOADS[args.workload]
     if args.workload == 'softmax_s16_384':

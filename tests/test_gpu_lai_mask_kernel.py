@@ -31,15 +31,20 @@ def test_kernel_mask_bits_equal_reference(N, w, bias, dtype):
     H = (N + dh - 1) // dh
     D = H * dh
     g = torch.Generator(device='cuda').manual_seed(100 * N + w)
-    qkv = (torch.randn(N, 3 * D, device='cuda', generator=g) * 0.3).to(dtype)
+    # every head gets the SAME q and k (and table) rows, so all heads compute one P and the pieces read from different heads
+    # belong to one softmax (the row sums below then check that nothing leaked outside the band)
+    rep = lambda rows: (torch.randn(rows, dh, device='cuda', generator=g) * 0.3).to(dtype).repeat(1, H)
+    qkv = torch.empty(N, 3 * D, device='cuda', dtype=dtype)
+    qkv[:, :D] = rep(N)
+    qkv[:, D:2 * D] = rep(N)
     v = torch.zeros(N, H, dh, device='cuda', dtype=dtype)
     j = torch.arange(N, device='cuda')
     v[j, j // dh, j % dh] = 1.0
     qkv[:, 2 * D:] = v.view(N, D)
     pk = pq = None
     if bias:
-        pk = (torch.randn(2 * N - 1, D, device='cuda', generator=g) * 0.3).to(dtype)
-        pq = (torch.randn(2 * N - 1, D, device='cuda', generator=g) * 0.3).to(dtype)
+        pk = rep(2 * N - 1).contiguous()
+        pq = rep(2 * N - 1).contiguous()
     q, k, vv = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
     scale = (dh * (3 if bias else 1)) ** -0.5
     out, _ = ops.attn_fwd(q, k, vv, 1, H, N, dh, qkv.stride(0), pk, pq, D, scale, w)
@@ -52,5 +57,5 @@ def test_kernel_mask_bits_equal_reference(N, w, bias, dtype):
         ref = np.unpackbits(want)[:N * N].reshape(N, N)
         bad = np.argwhere(ref != pattern)
         raise AssertionError(f'kernel mask differs from get_attn_mask({N}, {w}) at {len(bad)} positions, first {bad[:5].tolist()}')
-    # rows sum to 1 over the band: nothing leaked outside it
-    assert torch.allclose(P.sum(1), torch.ones(N, device='cuda'), atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+    # rows sum to 1 over the band: nothing leaked outside it (bf16: up to 2 w + 1 = 41 outputs, each rounded to 8 bits)
+    assert torch.allclose(P.sum(1), torch.ones(N, device='cuda'), atol=5e-2 if dtype == torch.bfloat16 else 1e-5)

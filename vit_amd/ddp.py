@@ -25,6 +25,23 @@ import torch
 import torch.distributed as dist
 
 
+def init_process_group(backend='nccl', device=None, **kw):
+    """torch.distributed.init_process_group (env:// rendezvous, as utils/ops.py:124-133 of the reference) with RCCL's stream
+    taken from the HIGH-PRIORITY class.  HIP runs its streams on a handful of hardware queues and streams that share one
+    run in turns: with a normal-priority RCCL stream the collectives landed on the main stream's queue and every bucket's
+    reduction ran IN LINE with backward instead of beside it (rocprofv3 trace, profiles/r03_reducer_*).  Priority classes
+    have queues of their own, and functional's side stream stays in the normal class."""
+    if backend == 'nccl':
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            if device is not None:
+                kw.setdefault('device_id', device)
+            return dist.init_process_group(backend, pg_options=opts, **kw)
+        except (AttributeError, TypeError):
+            pass
+    return dist.init_process_group(backend, **kw)
+
+
 class GradReducer:
     def __init__(self, module, bucket_mb=128, process_group=None, broadcast=True, comm_dtype=torch.float32,
                  always_reduce=False, reserve_cus=None):
@@ -41,6 +58,7 @@ class GradReducer:
         self._view_of = {}
         self._handles = []
         self._hooks = []
+        self._copies = []        # per bucket: (view, gradient) pairs waiting for the bucket's one multi-tensor copy
         self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == 'nccl' else dist.ReduceOp.SUM
         # comm_dtype: what travels over xGMI.  fp32 (default) reduces the slabs in place, bit-compatible with the
         # reference's DDP; bf16 halves the bytes per step (SURVEY 8(e) budgets 612 MB for the B preset instead of
@@ -114,18 +132,32 @@ class GradReducer:
     def _on_grad(self, p):
         view = self._view_of[p]
         g = p.grad
+        bi = self._bucket_of[p]
         if g is not view and g.data_ptr() != view.data_ptr():     # produced elsewhere: into the slab, once
-            view.copy_(g)
+            # not one copy kernel per parameter (a B-preset step made 349 of them, 5 us each, in line on the main
+            # stream): the pairs of a bucket go out as ONE multi-tensor copy right before its all-reduce
+            self._copies[bi].append((view, g))
             p.grad = view
         p._vitk_grad_slot = None
-        bi = self._bucket_of[p]
         pend = self._pending[bi]
         pend.discard(p)
         if not pend and self._launched is not None and not self._launched[bi]:
             self._launch(bi)
 
+    def _flush_copies(self, bi):
+        pairs = self._copies[bi]
+        if pairs:
+            same = [(v, g) for v, g in pairs if g.dtype == v.dtype and g.shape == v.shape]
+            if same:
+                torch._foreach_copy_([v for v, _ in same], [g for _, g in same])
+            for v, g in pairs:
+                if not (g.dtype == v.dtype and g.shape == v.shape):
+                    v.copy_(g)
+            pairs.clear()
+
     def _launch(self, bi):
         self._launched[bi] = True
+        self._flush_copies(bi)
         if self.world > 1 or self.always_reduce:
             flat = self.buckets[bi]
             if self.comm_dtype != torch.float32:
@@ -147,14 +179,18 @@ class GradReducer:
             return
         # No slab-wide zero-fill: every view is either written whole by the hook's copy or zeroed here because
         # a GEMM will accumulate into it (the slot protocol of functional.grad_slot); the pads were zeroed at build.
+        direct = []
         for ps in self._groups:
             for p in ps:
                 p.grad = None
                 if getattr(p, '_vitk_direct', False):       # set by the fused blocks on the weights they can write in place
                     view = self._view_of[p]
-                    view.zero_()
+                    direct.append(view)
                     p._vitk_grad_slot = view
+        if direct:
+            torch._foreach_zero_(direct)                    # a few multi-tensor fills instead of one kernel per weight
         self._pending = [set(ps) for ps in self._groups]
+        self._copies = [[] for _ in self._groups]
         self._launched = [False] * len(self.buckets)
 
     def finish(self):
@@ -163,6 +199,7 @@ class GradReducer:
             self._build()
             self._pending = [set() for _ in self.buckets]
             self._launched = [False] * len(self.buckets)
+            self._copies = [[] for _ in self.buckets]
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:       # a parameter got no gradient this step: reduce zeros for it
                 for p in self._pending[bi]:

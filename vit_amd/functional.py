@@ -163,10 +163,55 @@ _side_streams = {}
 _side_pending = {}
 
 
+def streams_overlap(a, b, device, cycles=1_500_000):
+    """True when kernels queued on streams ``a`` and ``b`` run at the same time.  HIP maps its streams onto a handful of
+    hardware queues (GPU_MAX_HW_QUEUES, 4 here) and two streams that share one run in turns, whatever the events between
+    them say.  Probe: one single-thread spin kernel (torch.cuda._sleep) on each, timed together."""
+    def run(both):
+        torch.cuda.synchronize(device)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(a)
+        b.wait_event(e0)
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+        e1.record(a)
+        if both:
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(cycles)
+        e2.record(b)
+        a.wait_event(e2)
+        e3 = torch.cuda.Event(enable_timing=True)
+        e3.record(a)
+        e3.synchronize()
+        return e0.elapsed_time(e3)
+    run(True)                                  # warm-up (first launch of the spin kernel)
+    one, two = run(False), run(True)
+    return two < 1.5 * one
+
+
 def _side_stream(device):
+    """The second stream of a device, on a hardware queue of its own.  Which queue a new stream gets depends on how many
+    streams the process made before (a process that initialised RCCL first got a side stream on the MAIN stream's
+    queue: every dW GEMM then ran in turn with the main stream's kernels, 83 ms per headline step instead of 65 -- seen in
+    a rocprofv3 trace, profiles/README.md r03).  So: take streams from torch's pool until one really overlaps the current
+    stream (probe above); normal priority first -- the high-priority class, which HIP keeps on queues of its own, is
+    left to RCCL's stream (ddp.init_process_group asks for it), so that the three never share a queue."""
     st = _side_streams.get(device)
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
+        cur = torch.cuda.current_stream(device)
+        cands, st = [], None
+        for attempt in range(6):
+            c = torch.cuda.Stream(device=device, priority=0 if attempt < 5 else -1)
+            cands.append(c)                    # keep the rejected ones alive until the choice is made: a freed stream's queue is re-used
+            if torch.cuda.is_current_stream_capturing() or streams_overlap(cur, c, device):
+                st = c
+                break
+        if st is None:
+            import warnings
+            warnings.warn('vit_amd: no stream found that overlaps the current one; the dW GEMMs will run in turn with the '
+                          'main stream (set VITK_DW_SPLITK= to give them the whole chip)')
+            st = cands[0]
+        _side_streams[device] = st
     return st
 
 

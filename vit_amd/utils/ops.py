@@ -58,7 +58,8 @@ def init_distributed_mode(args):
     else:
         args.device = 'cpu'
     if not dist.is_initialized():
-        dist.init_process_group(backend='nccl' if use_gpu else 'gloo', init_method='env://')
+        from ..ddp import init_process_group      # RCCL's stream in the high-priority class (a hardware queue of its own)
+        init_process_group('nccl' if use_gpu else 'gloo', init_method='env://')
     args.world_size = dist.get_world_size()
     args.rank = dist.get_rank()
 
