@@ -98,3 +98,49 @@ def test_attn_bwd(dtype, bias, w, B, N, H, dh):
     # the fused q|k|v bias gradient: column sums of dq | dk | dv over every token
     db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
     assert relerr(dbias, db_ref) < tol
+
+
+# The banded disentangled kernels of attention_lai.hip (bf16, head width 64, one chunk, 0 <= w <= 20): every LAI stage of
+# the reference (8 / 12 / 18 / 20), the 3- and 5-diagonal instances on both sides of w = 16, one-tile and 13-tile heads,
+# ragged last tiles, and a batch larger than the workgroups per head (20 > 256 / 16: a workgroup walks two batch elements
+# and keeps its table gradients across them).
+LAI_CASES = [(3, 65, 2, 64, 8), (3, 65, 2, 64, 20), (2, 208, 2, 64, 12), (2, 208, 2, 64, 18), (2, 100, 4, 64, 20),
+             (20, 33, 16, 64, 8), (20, 33, 16, 64, 18), (1, 197, 3, 64, 12), (1, 197, 3, 64, 18), (2, 197, 2, 64, 1),
+             (2, 197, 2, 64, 5), (2, 197, 2, 64, 16), (2, 197, 2, 64, 17), (2, 16, 2, 64, 15), (4, 21, 1, 64, 20),
+             (128, 197, 16, 64, 8), (128, 197, 16, 64, 20)]        # the last two: BASELINE.json's full shape (8 heads per workgroup)
+
+
+@pytest.mark.parametrize('B,N,H,dh,w', LAI_CASES)
+def test_lai_dis_kernels(B, N, H, dh, w):
+    from vit_amd import ops
+    dtype = torch.bfloat16
+    D = H * dh
+    qkv, pk, pq = make(B, N, H, dh, dtype, True, seed=5 * N + w)
+    q, k, v = views(qkv, B, N, H, dh)
+    scale = (dh * 3) ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, w)
+    f = lambda t: t.double().reshape(B, N, H, dh).clone().requires_grad_(True)
+    qr, kr, vr = f(q), f(k), f(v)
+    pkr = pk.double().view(-1, H, dh).clone().requires_grad_(True)
+    pqr = pq.double().view(-1, H, dh).clone().requires_grad_(True)
+    ref, lse_ref, _ = attention_ref(qr, kr, vr, pkr, pqr, scale, w)
+    assert relerr(out.view(B, N, H, dh), ref.detach()) < 1.5e-2
+    assert relerr(lse, lse_ref.detach()) < 2e-3
+    g = torch.Generator(device='cuda').manual_seed(11)
+    dout = torch.randn(B * N, D, device='cuda', generator=g).to(dtype)
+    dqkv = torch.full_like(qkv, float('nan'))
+    dq, dk, dv = views(dqkv, B, N, H, dh)
+    dpk = torch.zeros(2 * N - 1, D, device='cuda')
+    dpq = torch.zeros(2 * N - 1, D, device='cuda')
+    dbias = torch.ones(3 * D, device='cuda')
+    ops.attn_bwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, w, out, dout, lse,
+                 dq, dk, dv, dqkv.stride(0), dpk, dpq, dbias=dbias)
+    (ref * dout.double().view(B, N, H, dh)).sum().backward()
+    tol = 2e-2
+    assert relerr(dq.reshape(B, N, H, dh), qr.grad) < tol
+    assert relerr(dk.reshape(B, N, H, dh), kr.grad) < tol
+    assert relerr(dv.reshape(B, N, H, dh), vr.grad) < tol
+    assert relerr(dpk.view(-1, H, dh), pkr.grad) < tol
+    assert relerr(dpq.view(-1, H, dh), pqr.grad) < tol
+    db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
+    assert relerr(dbias, db_ref) < tol

@@ -47,15 +47,17 @@ def test_bench_with_forced_reducer_runs_in_process(monkeypatch):
     monkeypatch.setenv('MASTER_PORT', str(29700 + os.getpid() % 200))
     lines = []
     for extra in ([], ['--force-reducer']):
-        monkeypatch.setattr(sys, 'argv', ['bench.py', '--steps', '2', '--warmup', '1', '--batch', '32', '--no-cpu-baseline']
-                            + extra)
+        # three warm-up steps: the reducer builds its slabs on the first one and takes its direct-write slots from the second
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--steps', '4', '--warmup', '3', '--batch', '32', '--no-cpu-baseline',
+                                          '--no-isolated'] + extra)
+        print('bench in process:', extra or 'plain', flush=True)
         buf = io.StringIO()
         with redirect_stdout(buf):
             bench.main()
         lines.append(json.loads(buf.getvalue().strip().splitlines()[-1]))
     plain, red = lines
-    assert red['n_gpus'] == 1 and red['steps'] == 2 and red['value'] > 0
+    assert red['n_gpus'] == 1 and red['steps'] == 4 and red['value'] > 0
     assert red['roofline']['kernel'].startswith('gemm')
-    # same seed, same batch, three steps each: the reducer changes where gradients are summed, not what they are
+    # same seed, same batch, seven steps each: the reducer changes where gradients are summed, not what they are
     assert abs(plain['loss'] - red['loss']) < 2e-2, (plain['loss'], red['loss'])
     assert red['value'] > 0.8 * plain['value'], (plain['value'], red['value'])    # slabs + hooks + 1-rank all-reduce stay cheap

@@ -8,6 +8,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('VITK_LIB'):          # a variant build of the library (tools/lai_phases.sh)
+    from vit_amd import _lib
+    _lib.LIB_PATH = os.environ['VITK_LIB']
 from vit_amd import ops  # noqa: E402
 
 

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIB = os.path.join(LIBDIR, 'libvitk.so')
-SOURCES = ['runtime.hip', 'gemm.hip', 'gemm256.hip', 'norm_act.hip', 'attention.hip', 'attention_bwd.hip', 'attention_band.hip', 'favor.hip', 'favor_fast.hip', 'optim.hip', 'loss.hip']
+SOURCES = ['runtime.hip', 'gemm.hip', 'gemm256.hip', 'norm_act.hip', 'attention.hip', 'attention_bwd.hip', 'attention_band.hip', 'attention_lai.hip', 'favor.hip', 'favor_fast.hip', 'optim.hip', 'loss.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']
 
 

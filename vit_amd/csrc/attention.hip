@@ -207,27 +207,8 @@ template <typename T, int KT> static void attn_fwd_dispatch(const AttnFwdParams&
 }  // namespace vitk
 
 namespace vitk {
-struct BandParams {
-    const void *q, *k, *v;
-    long ld;
-    const void *pk, *pq;
-    long ld_p;
-    void* out;
-    long ldo;
-    float* lse;
-    const void* dout;
-    float* delta;
-    void *dq, *dk, *dv;
-    long ld_d;
-    int B, H, N, dh;
-    float scale;
-    int w;
-    __bf16* ds_ws;
-    DropParams drop;
-    float* dbias;
-};
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
-void band_launch(const BandParams& p, bool backward, hipStream_t st);
+bool band_launch(const BandParams& p, bool backward, hipStream_t st);
 }  // namespace vitk
 
 using namespace vitk;

@@ -23,7 +23,6 @@
 // softmax state / gradient accumulators stay in registers across groups -- and the next group's
 // rows replace them (two workgroup barriers per group).  Every LAI stage of the reference
 // (w = 8..20) is a single group; the unmasked disentangled stage of 197 tokens is five.
-#include <type_traits>
 #include "attn_common.h"
 
 namespace vitk {
@@ -47,26 +46,6 @@ constexpr int BAND_FWD_WAVES = 16;
 constexpr int BAND_FWD_THREADS = 64 * BAND_FWD_WAVES;
 static_assert(BAND_FWD_WAVES >= BAND_CH && BAND_WAVES * BAND_TPW >= BAND_CH, "a chunk's tiles all have an owner");
 
-struct BandParams {
-    const void *q, *k, *v;
-    long ld;
-    const void *pk, *pq;
-    long ld_p;
-    void* out;              // forward: written; backward: read
-    long ldo;
-    float* lse;             // forward: written; backward: read
-    const void* dout;
-    float* delta;           // backward: delta_i = dO_i . O_i, WRITTEN here (read by attn_bwd_rel_kernel)
-    void *dq, *dk, *dv;
-    long ld_d;
-    int B, H, N, dh;
-    float scale;
-    int w;
-    __bf16* ds_ws;          // backward: dS tiles, written by the dK / dV kernel, read by the dQ kernel and the table-gradient kernel
-    DropParams drop;        // dropout on the probabilities, element ((b*H + h)*N + i)*N + j of the stream (attention.hip)
-    float* dbias;           // backward, optional: [3 * H * dh] fp32 (q | k | v), += the column sums of dQ / dK / dV over all
-                            // tokens -- the bias gradient of the fused qkv projection, without a pass over dqkv
-};
 
 template <int DW, bool BIAS> struct BandCfg {
     static constexpr int DKB = (DW + 31) / 32;     // K blocks of a score product
@@ -271,19 +250,6 @@ __global__ __launch_bounds__(BAND_FWD_THREADS) void attn_fwd_band_kernel(const B
 }
 
 // ----------------------------------------------------------------------------------------- backward
-// Sum over the 16 lanes of a DPP row (the lanes that share lane >> 4), in every lane of the row: two quad
-// permutes and two row rotations, all on the VALU (a __shfl_xor would go through the LDS pipe).
-__device__ inline float row16_sum(float t) {
-    auto dpp = [](float x, auto ctrl) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-    };
-    t += dpp(t, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-    t += dpp(t, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-    t += dpp(t, std::integral_constant<int, 0x124>{});   // row_ror:4
-    t += dpp(t, std::integral_constant<int, 0x128>{});   // row_ror:8
-    return t;
-}
-
 // acc[tile][dt][r] = X^T[d = 16 dt + 4 g + r][row li]: sum over the wave's tiles and its 16 row lanes, then one LDS
 // atomic per (group, d) into dst[d]
 template <int TPW, int ND>
@@ -1027,7 +993,15 @@ template <int DW, bool BIAS> static void band_bwd_launch(const BandParams& p, in
     hipLaunchKernelGGL((attn_bwd_band_q_kernel<DW, BIAS>), dim3(p.H, p.B, chunks), dim3(BAND_FWD_THREADS), lds_q, st, p);
 }
 
-void band_launch(const BandParams& p, bool backward, hipStream_t st) {
+bool lai_eligible(const BandParams& p, bool backward);
+void lai_launch(const BandParams& p, bool backward, hipStream_t st);
+
+// Returns true when a backward launch has already produced the table gradients (p.dpk / p.dpq).
+bool band_launch(const BandParams& p, bool backward, hipStream_t st) {
+    if (lai_eligible(p, backward)) {     // banded + disentangled, one chunk, head width 64 (attention_lai.hip)
+        lai_launch(p, backward, st);
+        return backward;
+    }
     const int NT = (p.N + 15) / 16;
     int cmax = p.w >= 0 ? (p.w + 15) / 16 : NT - 1;
     if (cmax > NT - 1) cmax = NT - 1;
@@ -1045,6 +1019,7 @@ void band_launch(const BandParams& p, bool backward, hipStream_t st) {
         if (bias) VITK_BAND(80, true); else VITK_BAND(80, false);
     }
 #undef VITK_BAND
+    return false;
 }
 
 }  // namespace vitk

@@ -879,27 +879,8 @@ template <typename T, int KTW> static void bwd_dispatch(const AttnBwdParams& p, 
 }  // namespace vitk
 
 namespace vitk {
-struct BandParams {
-    const void *q, *k, *v;
-    long ld;
-    const void *pk, *pq;
-    long ld_p;
-    void* out;
-    long ldo;
-    float* lse;
-    const void* dout;
-    float* delta;
-    void *dq, *dk, *dv;
-    long ld_d;
-    int B, H, N, dh;
-    float scale;
-    int w;
-    __bf16* ds_ws;
-    DropParams drop;
-    float* dbias;
-};
 bool band_eligible(int dtype, int N, int dh, bool bias, int band_w);
-void band_launch(const BandParams& p, bool backward, hipStream_t st);
+bool band_launch(const BandParams& p, bool backward, hipStream_t st);
 }  // namespace vitk
 
 using namespace vitk;
@@ -992,8 +973,9 @@ extern "C" int vitk_attn_bwd(int dtype, int B, int H, int N, int dh, const void*
         // pass 1 leaves its dS tiles behind delta: for pass 2 and for the table-gradient kernel
         bp.ds_ws = reinterpret_cast<__bf16*>(p.delta + ((long)B * H * N + 63) / 64 * 64);
         p.ds_ws = bp.ds_ws;
-        band_launch(bp, true, stream);
-        if (pk) {
+        bp.dpk = dpk; bp.dpq = dpq; bp.ld_dp = ld_dp;
+        const bool tables_done = band_launch(bp, true, stream);     // attention_lai.hip sums the table gradients itself
+        if (pk && !tables_done) {
             const int dkb = (dh + 31) / 32;
             if (dkb == 1) relds_launch<1>(p, zgroups, stream);
             else if (dkb == 2) relds_launch<2>(p, zgroups, stream);

@@ -17,6 +17,7 @@
 // Pq[delta0+t].K_jj); they go through a per-wave LDS scratch, written row-wise and read back
 // along the diagonals t = ii - jj + 15.  Nothing of size N x N ever leaves the CU.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace vitk {
@@ -125,6 +126,43 @@ __device__ __forceinline__ void acc_to_frag(Frag<float>& f, const f32x4& a, cons
         f.v[4 + e] = b[e];
     }
 }
+
+// Sum over the 16 lanes of a DPP row (the lanes that share lane >> 4), in every lane of the row: two quad
+// permutes and two row rotations, all on the VALU (a __shfl_xor would go through the LDS pipe).
+__device__ inline float row16_sum(float t) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    t += dpp(t, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    t += dpp(t, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    t += dpp(t, std::integral_constant<int, 0x124>{});   // row_ror:4
+    t += dpp(t, std::integral_constant<int, 0x128>{});   // row_ror:8
+    return t;
+}
+
+// Parameters of the whole-head kernels (attention_band.hip, attention_lai.hip)
+struct BandParams {
+    const void *q, *k, *v;
+    long ld;
+    const void *pk, *pq;
+    long ld_p;
+    void* out;              // forward: written; backward: read
+    long ldo;
+    float* lse;             // forward: written; backward: read
+    const void* dout;
+    float* delta;           // backward: delta_i = dO_i . O_i, WRITTEN here (read by attn_bwd_rel_kernel)
+    void *dq, *dk, *dv;
+    long ld_d;
+    int B, H, N, dh;
+    float scale;
+    int w;
+    __bf16* ds_ws;          // backward: dS tiles, written by the dK / dV kernel, read by the dQ kernel and the table-gradient kernel
+    DropParams drop;        // dropout on the probabilities, element ((b*H + h)*N + i)*N + j of the stream (attention.hip)
+    float *dpk, *dpq;       // backward, with tables: fp32 table gradients [2N-1][ld_dp], accumulated into (attention_lai.hip;
+    long ld_dp;             // the whole-head kernels of attention_band.hip leave them to attn_bwd_relds_kernel)
+    float* dbias;           // backward, optional: [3 * H * dh] fp32 (q | k | v), += the column sums of dQ / dK / dV over all
+                            // tokens -- the bias gradient of the fused qkv projection, without a pass over dqkv
+};
 
 // Raw (unscaled) score tile for 16 queries x 16 keys.
 //   qf / kf : row fragments of the 16 queries / 16 keys (DKB head-dim blocks each)

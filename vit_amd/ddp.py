@@ -21,6 +21,8 @@ Design (MI355X first, not a DDP translation):
     step and left with ``grad = None`` so AdamW skips them exactly as in the reference; stock DDP
     would raise on them.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -30,15 +32,28 @@ def init_process_group(backend='nccl', device=None, **kw):
     taken from the HIGH-PRIORITY class.  HIP runs its streams on a handful of hardware queues and streams that share one
     run in turns: with a normal-priority RCCL stream the collectives landed on the main stream's queue and every bucket's
     reduction ran IN LINE with backward instead of beside it (rocprofv3 trace, profiles/r03_reducer_*).  Priority classes
-    have queues of their own, and functional's side stream stays in the normal class."""
+    have queues of their own, and functional's side stream stays in the normal class.
+
+    Only for a process that has not run the fused blocks yet (the reference's order too: init_distributed_mode, then the
+    model, train.py:631-635).  A high-priority RCCL stream made AFTER the process had trained on its main and side streams
+    left the next step's kernels pending for good (torch.cuda.synchronize() never returned; tools/diag_reducer_hang.py:
+    main stream, side stream and every bucket pending -- with a normal-priority RCCL stream the same sequence runs).  The
+    cause inside the runtime is not known; such a process gets the normal class, and the side stream is chosen again so
+    that the overlap probe sees the queues as they are now.  VITK_RCCL_HIGH_PRIORITY=0 / =1 forces either."""
     if backend == 'nccl':
-        try:
-            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            if device is not None:
-                kw.setdefault('device_id', device)
-            return dist.init_process_group(backend, pg_options=opts, **kw)
-        except (AttributeError, TypeError):
-            pass
+        if device is not None:
+            kw.setdefault('device_id', device)
+        from . import functional as VF
+        want = os.environ.get('VITK_RCCL_HIGH_PRIORITY')
+        high = (want != '0') if want in ('0', '1') else not VF._side_streams
+        if not high and VF._side_streams:
+            VF.forget_side_streams()
+        if high:
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                return dist.init_process_group(backend, pg_options=opts, **kw)
+            except (AttributeError, TypeError):
+                pass
     return dist.init_process_group(backend, **kw)
 
 

@@ -215,6 +215,14 @@ def _side_stream(device):
     return st
 
 
+def forget_side_streams():
+    """Drop the chosen side streams (after everything queued on them has finished): the next fused backward probes again."""
+    for dev, st in list(_side_streams.items()):
+        st.synchronize()
+    _side_streams.clear()
+    _side_pending.clear()
+
+
 def side_join(device):
     """Main stream waits for the dW GEMMs queued on the side stream since the last join."""
     keep = _side_pending.get(device)
