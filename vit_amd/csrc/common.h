@@ -133,6 +133,48 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     return fmaf(0.5f, erfv, 0.5f) + x * (0.39894228040143267794f * e);
 }
 
+// erf-GELU without transcendentals, two elements per instruction (v_pk_fma_f32): round 3's form of the bf16 epilogues.
+//   gelu(x)  = x / 2 + E(x),   E(x) = x (Phi(x) - 1/2)   even, = x^2 P(z) on |x| <= 4,  z = x^2 / 8 - 1 in [-1, 1]
+//   gelu'(x) = 1 / 2 + x R(z)                                                                (R fitted on its own)
+// P, R: degree-8 least-squares fits on Chebyshev nodes (tools/fit_gelu.py), evaluated by Horner in z; |x| > 4 continues the
+// value at 4 with slope 1 / 0 (gelu) or holds it (gelu').  Max |error| in fp32 Horner: 9.5e-5 (gelu, in the tails; 3e-5
+// inside), 6e-4 (gelu', tails; 1.1e-4 inside) -- an order below the 2^-9 rounding of the bf16 value it is stored as, and
+// 10.5 VALU per element where the exp2 / rcp form above costs 12 + two quarter-rate ops: the fc1 forward and fc2 dX GEMMs
+// spent a fifth of their time in this arithmetic with the matrix cores idle.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_clamp2(f32x2 x) {
+    return f32x2{__builtin_amdgcn_fmed3f(x[0], -4.f, 4.f), __builtin_amdgcn_fmed3f(x[1], -4.f, 4.f)};
+}
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    const f32x2 xc = gelu_clamp2(x);
+    const f32x2 z = xc * (xc * 0.125f) - 1.0f;
+    f32x2 p = {1.605170928e-03f, 1.605170928e-03f};
+    p = p * z + -3.991263335e-03f;
+    p = p * z + 5.828486749e-03f;
+    p = p * z + -1.154668287e-02f;
+    p = p * z + 2.266773498e-02f;
+    p = p * z + -3.713346277e-02f;
+    p = p * z + 5.591522291e-02f;
+    p = p * z + -8.430131655e-02f;
+    p = p * z + 1.759501642e-01f;
+    const f32x2 s = {x[0] + (__builtin_fabsf(x[0]) - __builtin_fabsf(xc[0])), x[1] + (__builtin_fabsf(x[1]) - __builtin_fabsf(xc[1]))};
+    return s * 0.5f + (xc * xc) * p;
+}
+__device__ __forceinline__ f32x2 gelu_grad_poly2(f32x2 x) {
+    const f32x2 xc = gelu_clamp2(x);
+    const f32x2 z = xc * (xc * 0.125f) - 1.0f;
+    f32x2 r = {1.995524858e-02f, 1.995524858e-02f};
+    r = r * z + -4.264639257e-02f;
+    r = r * z + 4.136232702e-02f;
+    r = r * z + -6.191498239e-02f;
+    r = r * z + 1.028313072e-01f;
+    r = r * z + -1.185188937e-01f;
+    r = r * z + 1.140870964e-01f;
+    r = r * z + -1.132650675e-01f;
+    r = r * z + 1.832627819e-01f;
+    return xc * r + 0.5f;
+}
+
 // ---------------------------------------------------------------------------------------- dropout
 // Counter-based keep mask: element `idx` of dropout stream (seed, offset) is kept iff a 32-bit hash of
 // (seed, offset, idx) is >= thresh = round(p * 2^32).  Stateless, so a backward kernel regenerates the mask

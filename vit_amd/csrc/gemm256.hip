@@ -170,13 +170,21 @@ __device__ __forceinline__ void epi8_regs(const GemmParams& p, long row, int n8,
             *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.aux_out) + row * p.ld_aux + n8) = o;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 y = gelu_poly2(f32x2{v[e], v[e + 1]});
+            v[e] = y[0];
+            v[e + 1] = y[1];
+        }
     } else if (p.act == ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     } else if (SIDE && p.act == ACT_DGELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)side[e]);
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 d = gelu_grad_poly2(f32x2{(float)side[e], (float)side[e + 1]});
+            v[e] *= d[0];
+            v[e + 1] *= d[1];
+        }
     } else if (SIDE && p.act == ACT_DRELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)side[e] > 0.f ? v[e] : 0.f;
