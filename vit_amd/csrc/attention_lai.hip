@@ -401,16 +401,18 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
     const int KBT = (G.TW + 31) / 32, NDT = (G.TW + 15) / 16;
     const int h = blockIdx.x;
 
+    // P2C sits between the images and C2P, C2P in front of dC2P: the diagonal walks below read every element of a tile,
+    // also those past either end of the sequence, and discard them -- those reads land in the workgroup's own LDS
     T* img0 = reinterpret_cast<T*>(smem);                 // K, then Q, then K
     T* img1 = img0 + NR * ASTR;                           // V, then dO
-    T* dcp = img1 + NR * ASTR;                            // dC2P, then dP2C: [NR][48]
-    T* tabk = dcp + NR * TLD;                             // Pk_b, Pq_b: [48][ASTR], rows past the band zero
+    T* tabk = img1 + NR * ASTR;                           // Pk_b, Pq_b: [48][ASTR], rows past the band zero
     T* tabq = tabk + TLD * ASTR;
-    float* lse2s = reinterpret_cast<float*>(tabq + TLD * ASTR);
+    float* P2C = reinterpret_cast<float*>(tabq + TLD * ASTR);    // [N][LDB]
+    float* C2P = P2C + N * LDB;
+    T* dcp = reinterpret_cast<T*>(C2P + N * LDB);         // dC2P, then dP2C: [NR][48]  (2 N LDB floats: a multiple of 16 bytes)
+    float* lse2s = reinterpret_cast<float*>(dcp + NR * TLD);
     float* dls = lse2s + NR;
     float* colacc = dls + NR;                             // [3][64]: column sums of dQ | dK | dV over this workgroup's heads
-    float* C2P = colacc + 3 * 64;                         // [N][LDB]
-    float* P2C = C2P + N * LDB;
 
     const T* PK = reinterpret_cast<const T*>(p.pk) + h * 64;
     const T* PQ = reinterpret_cast<const T*>(p.pq) + h * 64;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                 l2 = row < N ? lraw * LOG2E : 0.f;
                 if (g == 0) {
                     lse2s[row] = l2;
-                    dls[row] = dlt;
+                    dls[row] = dlt * p.scale;             // pre-scaled: dS = P (dP scale - delta scale)
                 }
                 for (int i = lane; i < 16 * TLD * 2 / 16; i += 64)   // own dC2P rows: zero (entries outside [0, N) stay so)
                     reinterpret_cast<u32x4*>(dcp + 16 * wave * TLD)[i] = u32x4{0, 0, 0, 0};
@@ -478,6 +480,11 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
         // ---- phase B: query-stationary (lane = query `row`): dQ, dC2P --------------------------------------------
         if (own) {
             const int qt = wave;
+            const int tq0 = row < N ? li - 4 * g - 16 * CM + w : 1 << 20;                // t of element (ci = 0, r = 0)
+            const float* pcB = C2P + rown * LDB + (li - 4 * g - 16 * CM + w) - 3;
+            const float* ppB = P2C + (16 * (qt - CM) + 4 * g) * LDB + (li - 4 * g - 16 * CM + w) + 16 * (NC - 1);
+            T* dcprow = dcp + row * TLD;
+            const float dls_own = dlt * p.scale;
             f32x4 dq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -494,7 +501,6 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                         continue;
                     }
                     const int kt = qt + CM - ci;
-                    const bool live = kt >= 0 && kt < G.NT;
                     ktc[u] = min(max(kt, 0), G.NT - 1);
                     f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -505,17 +511,20 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                         s = mma(kf, qf[kb], s);           // raw[query li][key 4g + r]
                         dp = mma(vf, dof[kb], dp);        // dP[query li][key 4g + r]
                     }
+                    // element r: key j = j0 + r, band row t = t0 - r; (unsigned) compares cover t < 0, j < 0 (tile in front
+                    // of the sequence) and, through the poisoned t of a query past the sequence, i >= N
+                    const int j0 = 16 * kt + 4 * g, t0 = tq0 + 16 * ci;
+                    const float* pc = pcB + 16 * ci;                                     // C2P[i][t0 - r]  = pc[3 - r]
+                    const float* pp = ppB + (NC - 1 - ci) * (16 * LDB - 16);             // P2C[j0 + r][t0 - r] = pp[r (LDB - 1)]
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * kt + 4 * g + r;
-                        const int t = row - j + w;
-                        const bool ok = live && j < N && row < N && t >= 0 && t < G.TW;
-                        const int tt = ok ? t : 0, jj = ok ? j : 0;
-                        const float raw = s[r] + C2P[rown * LDB + tt] + P2C[jj * LDB + tt];
-                        const float pe = ok ? __builtin_amdgcn_exp2f(raw * sc2 - l2) : 0.f;
-                        const float d = pe * (dp[r] - dlt) * p.scale;
+                        const bool ok = (unsigned)(t0 - r) < (unsigned)G.TW && (unsigned)(j0 + r) < (unsigned)N;
+                        const float raw = s[r] + pc[3 - r] + pp[r * (LDB - 1)];
+                        const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(raw, sc2, -l2) : -INFINITY);
+                        const float d = pe * fmaf(dp[r], p.scale, -dls_own);
                         dsv[u][r] = d;
-                        if (ok) dcp[row * TLD + t] = (__bf16)d;
+                        // outside the band d = 0: written to a pad column (47) of the own row instead of branching
+                        dcprow[ok ? t0 - r : TLD - 1] = (__bf16)d;
                     }
                 }
                 Frag<T> bs;
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                 }
             }
             wave_lds_sync();
-            lai_table_product(dq, tabk, dcp + row * TLD, KBT, lane);         // dQ_i += sum_t dC2P[i][t] Pk_b[t]
+            lai_table_product(dq, tabk, dcprow, KBT, lane);         // dQ_i += sum_t dC2P[i][t] Pk_b[t]
             if (row < N) {
                 T* dQ = reinterpret_cast<T*>(p.dq) + ((long)b * N + row) * p.ld_d + h * 64;
 #pragma unroll
@@ -557,6 +566,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
         // ---- phase C: key-stationary (lane = key `row`): P and dS again, dK, dV, dP2C --------------------------
         if (own) {
             const int kt = wave;
+            const int tk0 = row < N ? 4 * g - li - 16 * CM + w : 1 << 20;                // t of element (ci = 0, r = 0)
+            const float* ppC = P2C + rown * LDB + (4 * g - li - 16 * CM + w);
+            const float* pcC = C2P + (16 * (kt - CM) + 4 * g) * LDB + (4 * g - li - 16 * CM + w);
+            T* dcprow = dcp + row * TLD;
             for (int i = lane; i < 16 * TLD * 2 / 16; i += 64)
                 reinterpret_cast<u32x4*>(dcp + 16 * wave * TLD)[i] = u32x4{0, 0, 0, 0};
             f32x4 dk[4], dv[4];
@@ -579,7 +592,6 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                         continue;
                     }
                     const int qt = kt + ci - CM;
-                    const bool live = qt >= 0 && qt < G.NT;
                     qtc[u] = min(max(qt, 0), G.NT - 1);
                     f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -592,18 +604,18 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                     }
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2s + 16 * qtc[u] + 4 * g);   // queries 4g .. 4g+3
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(dls + 16 * qtc[u] + 4 * g);
+                    const int i0 = 16 * qt + 4 * g, t0 = tk0 + 16 * ci;                  // query i0 + r, band row t0 + r
+                    const float* pc = pcC + ci * (16 * LDB + 16);                        // C2P[i0 + r][t0 + r] = pc[r (LDB + 1)]
+                    const float* pp = ppC + 16 * ci;                                     // P2C[j][t0 + r]      = pp[r]
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * qt + 4 * g + r;
-                        const int t = i - row + w;
-                        const bool ok = live && i < N && row < N && t >= 0 && t < G.TW;
-                        const int tt = ok ? t : 0, ii = ok ? i : 0;
-                        const float raw = s[r] + C2P[ii * LDB + tt] + P2C[rown * LDB + tt];
-                        const float pe = ok ? __builtin_amdgcn_exp2f(raw * sc2 - l4[r]) : 0.f;
-                        const float d = pe * (dp[r] - d4[r]) * p.scale;
+                        const bool ok = (unsigned)(t0 + r) < (unsigned)G.TW && (unsigned)(i0 + r) < (unsigned)N;
+                        const float raw = s[r] + pc[r * (LDB + 1)] + pp[r];
+                        const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(raw, sc2, -l4[r]) : -INFINITY);
+                        const float d = pe * fmaf(dp[r], p.scale, -d4[r]);
                         pt[u][r] = pe;
                         dsv[u][r] = d;
-                        if (ok) dcp[row * TLD + t] = (__bf16)d;
+                        dcprow[ok ? t0 + r : TLD - 1] = (__bf16)d;
                     }
                 }
                 Frag<T> bp, bs;
@@ -619,7 +631,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                 }
             }
             wave_lds_sync();
-            lai_table_product(dk, tabq, dcp + row * TLD, KBT, lane);         // dK_j += sum_t dP2C[j][t] Pq_b[t]
+            lai_table_product(dk, tabq, dcprow, KBT, lane);         // dK_j += sum_t dP2C[j][t] Pq_b[t]
             if (row < N) {
                 T* dK = reinterpret_cast<T*>(p.dk) + ((long)b * N + row) * p.ld_d + h * 64;
                 T* dV = reinterpret_cast<T*>(p.dv) + ((long)b * N + row) * p.ld_d + h * 64;
