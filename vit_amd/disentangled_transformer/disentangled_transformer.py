@@ -284,22 +284,17 @@ class DisentangledEncoderLayer(ComputeDtypeMixin, nn.Module):
         ``x_ext``: x2 is the output of the previous layer's forward2d with the same band (its buffer
         already has the rows the relative table rides in: functional.DisLayerFn)."""
         a = self.dis_attn
-        if self.dropout_active():
-            # training with dropout (the reference default, train.py:79): the layer as separate autograd nodes with the
-            # dropout sites of the reference in its order -- table rows, probabilities, attention output, block output
-            if x_ext:
-                raise ValueError('DisentangledEncoderLayer: the extended-row layout is not used with dropout')
-            p_pos = a.pos_dropout.p if a.relative_attention else 0.
-            bd = VF.dropout(band, p_pos) if (band is not None and p_pos > 0) else band
-            q, k, v = a.query_proj, a.key_proj, a.value_proj
-            ctx = VF.DisAttentionFn.apply(x2, bd, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
-                                          (B, N, a.num_attention_heads, a.scale(),
-                                           a._width(0 if epoch is None else epoch), VD.next_stream(a.dropout.p)))
-            return self._post_attention(ctx, x2)
         if self.layer_norm_AttnOut.eps != self.layer_norm_out.eps:
             raise NotImplementedError('DisentangledEncoderLayer: the two LayerNorms must share eps')
+        drops = None
+        if self.dropout_active():
+            # training with dropout (the reference default, train.py:79): one stream per dropout site of the reference, drawn
+            # in its order -- table rows, probabilities, attention output, block output -- and handed to the fused node
+            p_pos = a.pos_dropout.p if (a.relative_attention and band is not None) else 0.
+            p1, p2 = self._drop_ps()
+            drops = (VD.next_stream(p_pos), VD.next_stream(a.dropout.p), VD.next_stream(p1), VD.next_stream(p2))
         cfg = (B, N, a.num_attention_heads, self.layer_norm_out.eps, a.scale(), a._width(0 if epoch is None else epoch),
-               'gelu', bool(x_ext and band is not None))
+               'gelu', bool(x_ext and band is not None), drops)
         q, k, v = a.query_proj, a.key_proj, a.value_proj
         return VF.DisLayerFn.apply(x2, band, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
                                    self.dense_AttnOut.weight, self.dense_AttnOut.bias,
@@ -374,7 +369,7 @@ class DisentangledEncoder(ComputeDtypeMixin, nn.Module):
         for i, layer in enumerate(self.layers):
             if band is None:
                 band = layer.dis_attn.band_for(rel, N, dt)   # identical for every (cloned) layer
-            x2 = layer.forward2d(x2, band, B, N, epoch, x_ext=i > 0 and not layer.dropout_active())
+            x2 = layer.forward2d(x2, band, B, N, epoch, x_ext=i > 0)
         return x2
 
     def forward(self, src, pos=None, epoch=None):

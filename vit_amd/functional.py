@@ -501,12 +501,16 @@ def dropout(x2d, p, res=None):
 
 
 # --------------------------------------------------------------------------- fused encoder blocks
-def _mlp_fwd(x, w1, b1, w2, b2, act, residual):
-    """y = act(x W1^T + b1) W2^T + b2 + residual.  Returns y, hmid, pre (pre is None for relu)."""
+def _mlp_fwd(x, w1, b1, w2, b2, act, residual, drop_out=NO_DROP):
+    """y = dropout(act(x W1^T + b1) W2^T + b2) + residual.  Returns y, hmid, pre (pre is None for relu)."""
     fwd_code, _ = _act_codes(act)
     pre = torch.empty(x.shape[0], w1.shape[0], device=x.device, dtype=x.dtype) if act == 'gelu' else None
     hmid = ops.gemm(x, w1, bias=b1, act=fwd_code, aux_out=pre)
-    y = ops.gemm(hmid, w2, bias=b2, residual=residual)
+    if drop_out[0] > 0.0:
+        y = ops.gemm(hmid, w2, bias=b2)
+        y = ops.dropout(y, drop_out, res=residual, out=y)
+    else:
+        y = ops.gemm(hmid, w2, bias=b2, residual=residual)
     return y, hmid, pre
 
 
@@ -639,12 +643,19 @@ class DisLayerFn(torch.autograd.Function):
     dqkv_ext = [dqkv ; (dPq | dPk | 0)] gives the bias / weight gradients of the shared projections
     and dband from the same three GEMMs as the tokens -- no 393-row GEMMs, extra column sums or
     accumulate passes.  cfg[7] (``x_ext``) says that x is the head of a buffer that already has
-    the tail rows allocated (the previous layer's output), so nothing is copied."""
+    the tail rows allocated (the previous layer's output), so nothing is copied.
+
+    cfg[8] (optional): the layer's four dropout streams (p, seed, offset) in the reference's order -- relative rows
+    (pos_dropout, :332/:883), probabilities (:343/:915, inside the attention kernels), attention output
+    (dropout_AttnOut, :189), block output (dropout_out, :195).  The reference trains with dropout 0.1 by default
+    (train.py:79): the node keeps its layout, its side-stream weight-gradient GEMMs and the gradient slots with it; the
+    dropped tensors are regenerated in backward from the three numbers, nothing is stored."""
 
     @staticmethod
     def forward(ctx, x, band, wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wi, bi, wout, bout, g2, be2, cfg):
         B, N, H, eps, scale, w, act = cfg[:7]
         x_is_ext = len(cfg) > 7 and cfg[7]
+        d_pos, d_attn, d_o1, d_o2 = cfg[8] if len(cfg) > 8 and cfg[8] is not None else (NO_DROP,) * 4
         M1, D = x.shape
         dh = D // H
         dt = x.dtype
@@ -662,7 +673,10 @@ class DisLayerFn(torch.autograd.Function):
             else:
                 x_ext = torch.empty(ME, D, device=x.device, dtype=dt)
                 x_ext[:M1].copy_(x)
-            x_ext[M1:M1 + R].copy_(band)
+            if d_pos[0] > 0.0:
+                ops.dropout(band, d_pos, out=x_ext[M1:M1 + R])
+            else:
+                x_ext[M1:M1 + R].copy_(band)
             x_ext[M1 + R:].zero_()
             x = x_ext[:M1]
             qkv_ext = ops.gemm(x_ext, wqkv, bias=bqkv)
@@ -673,10 +687,14 @@ class DisLayerFn(torch.autograd.Function):
             x_ext, qkv_ext = x, ops.gemm(x, wqkv, bias=bqkv)
             qkv = qkv_ext
             y_ext = torch.empty(M1, D, device=x.device, dtype=dt)
-        attn, lse = _attn_fwd(qkv, B, N, H, dh, tables, scale, w)
-        s1 = ops.gemm(attn, shadow(wo, dt), bias=_f32(bo), residual=x)
+        attn, lse = _attn_fwd(qkv, B, N, H, dh, tables, scale, w, d_attn)
+        if d_o1[0] > 0.0:
+            s1 = ops.gemm(attn, shadow(wo, dt), bias=_f32(bo))
+            s1 = ops.dropout(s1, d_o1, res=x, out=s1)
+        else:
+            s1 = ops.gemm(attn, shadow(wo, dt), bias=_f32(bo), residual=x)
         a, mean1, rstd1 = ops.layernorm_fwd(s1, _f32(g1), _f32(be1), eps)
-        s2, hmid, pre = _mlp_fwd(a, shadow(wi, dt), _f32(bi), shadow(wout, dt), _f32(bout), act, a)
+        s2, hmid, pre = _mlp_fwd(a, shadow(wi, dt), _f32(bi), shadow(wout, dt), _f32(bout), act, a, d_o2)
         y, mean2, rstd2 = ops.layernorm_fwd(s2, _f32(g2), _f32(be2), eps, out=y_ext[:M1])
         ctx.save_for_backward(x_ext, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv_ext, attn, lse, s1, mean1, rstd1,
                               a, hmid, pre, s2, mean2, rstd2)
@@ -688,6 +706,7 @@ class DisLayerFn(torch.autograd.Function):
         (x_ext, band, wq, wk, wv, wo, g1, wi, wout, g2, qkv_ext, attn, lse, s1, mean1, rstd1, a, hmid, pre, s2,
          mean2, rstd2) = ctx.saved_tensors
         B, N, H, eps, scale, w, act = ctx.cfg[:7]
+        d_pos, d_attn, d_o1, d_o2 = ctx.cfg[8] if len(ctx.cfg) > 8 and ctx.cfg[8] is not None else (NO_DROP,) * 4
         M1 = B * N
         ME, D = x_ext.shape
         dh = D // H
@@ -700,9 +719,14 @@ class DisLayerFn(torch.autograd.Function):
         zp = _ZeroPool(x_ext.device, D, D, D, D, D, D, D, F, D, 3 * D, R * 2 * D, 3 * D * D,
                        0 if s_wi is not None else F * D, 0 if s_wout is not None else D * F, 0 if s_wo is not None else D * D)
         dg2, dbe2, dbout = zp.take(D), zp.take(D), zp.take(D)
-        ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2, dxsum=dbout)
-        da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2, a, wi, wout, act, hmid, pre, ds2,
-                                              db1=zp.take(F), db2=dbout, db2_done=True,
+        if d_o2[0] > 0.0:
+            # ds2 goes on to the residual as it is; dense_out sees it through the output dropout's mask
+            ds2 = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2)
+            ds2_lin = ops.dropout(ds2, d_o2)
+        else:
+            ds2 = ds2_lin = ops.layernorm_bwd(dy, s2, mean2, rstd2, _f32(g2), dg2, dbe2, dxsum=dbout)
+        da, dwi, dbi, dwout, dbout = _mlp_bwd(ds2_lin, a, wi, wout, act, hmid, pre, ds2,
+                                              db1=zp.take(F), db2=dbout, db2_done=d_o2[0] == 0.0,
                                               dw1=s_wi if s_wi is not None else zp.take(F, D),
                                               dw2=s_wout if s_wout is not None else zp.take(D, F))
         if dwi is s_wi:
@@ -712,11 +736,16 @@ class DisLayerFn(torch.autograd.Function):
         dg1, dbe1, dbo = zp.take(D), zp.take(D), zp.take(D)
         ds1_ext = _ext_workspace('ds1', ME, D, dt, x_ext.device, (M1, R)) if band is not None else \
             torch.empty(ME, D, device=x_ext.device, dtype=dt)
-        ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
-        dwo = _dw(ds1, attn, out=s_wo if s_wo is not None else zp.take(D, D), side=True)
+        if d_o1[0] > 0.0:
+            ds1 = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1])
+            ds1_lin = ops.dropout(ds1, d_o1)
+            _colsum(ds1_lin, out=dbo, side=True)
+        else:
+            ds1 = ds1_lin = ops.layernorm_bwd(da, s1, mean1, rstd1, _f32(g1), dg1, dbe1, out=ds1_ext[:M1], dxsum=dbo)
+        dwo = _dw(ds1_lin, attn, out=s_wo if s_wo is not None else zp.take(D, D), side=True)
         if dwo is s_wo:
             dwo = dwo.detach()
-        dattn = _dx(ds1, wo)
+        dattn = _dx(ds1_lin, wo)
         tables = dtab = None
         if band is not None:
             dqkv_ext = _ext_workspace('dqkv', ME, 3 * D, dt, x_ext.device, (M1, R))
@@ -725,7 +754,8 @@ class DisLayerFn(torch.autograd.Function):
         else:
             dqkv_ext = torch.empty(ME, 3 * D, device=x_ext.device, dtype=dt)
         dbqkv = zp.take(3 * D)             # token rows: summed by the attention backward; table rows: below
-        _attn_bwd(qkv_ext[:M1], B, N, H, dh, tables, scale, w, attn, dattn, lse, dtab=dtab, dqkv=dqkv_ext[:M1], dbias=dbqkv)
+        _attn_bwd(qkv_ext[:M1], B, N, H, dh, tables, scale, w, attn, dattn, lse, dtab=dtab, dqkv=dqkv_ext[:M1], drop=d_attn,
+                  dbias=dbqkv)
         if band is not None:
             dqkv_ext[M1:M1 + R, :2 * D].copy_(dtab)               # (dPq | dPk) in compute dtype
             ops.colsum(dtab, out=dbqkv[:2 * D])                   # the table rows went through the same projections
@@ -734,6 +764,8 @@ class DisLayerFn(torch.autograd.Function):
         side_join(x_ext.device)
         dx = dx_ext[:M1]
         dband = dx_ext[M1:M1 + R] if band is not None else None
+        if dband is not None and d_pos[0] > 0.0:
+            dband = ops.dropout(dband, d_pos)         # the rows went in through pos_dropout
         dwq, dwk, dwv = dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:]
         dbq, dbk, dbv = dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:]
         return (dx, dband, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg1, dbe1, dwi, dbi, dwout, dbout, dg2, dbe2,
