@@ -200,7 +200,7 @@ __device__ __forceinline__ uint32_t lai_mask_k(int kt, int li, int g, int N, int
 
 // grid (H, groups): the workgroup walks batch elements b = group, group + groups, ... of head h; the next element's rows
 // are requested before the current one is worked on.  NC = live tile diagonals of a row: 3 (w <= 16) or 5.
-template <int NC>
+template <int NC, bool DROP>
 __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandParams p, int groups) {
     using T = __bf16;
     constexpr int ASTR = LAI_ASTR, LDB = LAI_LDB, CM = (NC - 1) / 2, NP = (NC + 1) / 2;
@@ -262,14 +262,16 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
             lai_put_rows(Vs, nv, qi, lane);
             lai_bias_rows(tabk, tabq, G, qf, nk, C2P + qin * LDB, P2C + qin * LDB, qi < N, lane);
         }
-        {   // the next batch element's rows (the last one asks for its own again: no branch around the loads)
+        auto prefetch = [&]() {   // the next batch element's rows (the last one asks for its own again: no branch around the loads)
             const long o = (long)min(b + groups, p.B - 1) * hb;
             lai_row_frags(nq, Qh + o, p.ld, fr, N, lane);
             lai_row_frags(nk, Kh + o, p.ld, fr, N, lane);
             lai_row_frags(nv, Vh + o, p.ld, fr, N, lane);
-        }
+        };
+        if (!DROP) prefetch();    // (with dropout the 24 registers they land in are needed for the mask hashes: asked for below)
         lai_barrier();
         if (own && VITK_LAI_STOP != 2) {
+            const uint64_t dhead = (uint64_t)(b * p.H + h) * (uint64_t)N;
             f32x4 sc[NC];
             float m = -INFINITY;
 #pragma unroll
@@ -292,14 +294,19 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             const float mref = (m == -INFINITY) ? 0.f : m;
             float ls = 0.f;
+            const uint64_t drow = DROP ? (dhead + (uint64_t)qin) * (uint64_t)N : 0;      // this query's row of the dropout stream
 #pragma unroll
-            for (int ci = 0; ci < NC; ++ci)
+            for (int ci = 0; ci < NC; ++ci) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(sc[ci][r] - mref);
                     ls += pv;
-                    sc[ci][r] = pv;
+                    // dropout (reference :915): the normaliser keeps every probability, P V sees the dropped ones; element
+                    // ((b H + h) N + i) N + j of the stream as in the other attention kernels (a masked element is 0 anyway)
+                    sc[ci][r] = DROP ? pv * drop_mul(p.drop, drow + (uint64_t)(uint32_t)(16 * (qt + CM - ci) + 4 * g + r)) : pv;
                 }
+                if (DROP) __builtin_amdgcn_sched_barrier(0);      // one tile's hashes at a time (20 interleaved chains spill)
+            }
             ls += __shfl_xor(ls, 16, 64);
             ls += __shfl_xor(ls, 32, 64);
             if (VITK_LAI_STOP == 3) {
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
                 }
             }
         }
+        if (DROP) prefetch();
         lai_barrier();            // everybody is done with the images and P2C before the next element's rows land in them
     }
 }
@@ -388,7 +396,7 @@ __device__ __forceinline__ f32x4 lai_table_grad(f32x4 acc, const __bf16* dcp, co
 }
 
 // grid (H, groups): the workgroup walks batch elements b = group, group + groups, ... of head h.
-template <int NC>
+template <int NC, bool DROP>
 __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandParams p, int groups) {
     using T = __bf16;
     constexpr int ASTR = LAI_ASTR, TLD = LAI_TLD, CM = (NC - 1) / 2, NP = (NC + 1) / 2;
@@ -434,6 +442,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
         const T* dO = reinterpret_cast<const T*>(p.dout) + (long)b * N * p.ldo + h * 64;
         const T* O = reinterpret_cast<const T*>(p.out) + (long)b * N * p.ldo + h * 64;
         const float* lse = p.lse + ((long)b * p.H + h) * N;
+        const uint64_t dhead = (uint64_t)(b * p.H + h) * (uint64_t)N;      // first row of this head in the dropout stream
         // per-thread offsets are invariants of this loop: hoisted out of it they alone overflow the 128 registers of a
         // 16-wave workgroup; recomputed per head they are a few VALU instructions
         int stid = tid;
@@ -521,7 +530,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                         const bool ok = (unsigned)(t0 - r) < (unsigned)G.TW && (unsigned)(j0 + r) < (unsigned)N;
                         const float raw = s[r] + pc[3 - r] + pp[r * (LDB - 1)];
                         const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(raw, sc2, -l2) : -INFINITY);
-                        const float d = pe * fmaf(dp[r], p.scale, -dls_own);
+                        // dropout: dP = (dO V^T) * keep / (1 - p); delta is unchanged (O was made from the dropped P)
+                        const float dm = DROP ? drop_mul(p.drop, (dhead + (uint64_t)rown) * (uint64_t)N + (uint64_t)(uint32_t)(j0 + r))
+                                              : 1.f;
+                        const float d = pe * fmaf(dp[r] * dm, p.scale, -dls_own);
                         dsv[u][r] = d;
                         // outside the band d = 0: written to a pad column (47) of the own row instead of branching
                         dcprow[ok ? t0 - r : TLD - 1] = (__bf16)d;
@@ -612,8 +624,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                         const bool ok = (unsigned)(t0 + r) < (unsigned)G.TW && (unsigned)(i0 + r) < (unsigned)N;
                         const float raw = s[r] + pc[r * (LDB + 1)] + pp[r];
                         const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(raw, sc2, -l4[r]) : -INFINITY);
-                        const float d = pe * fmaf(dp[r], p.scale, -d4[r]);
-                        pt[u][r] = pe;
+                        const float dm = DROP ? drop_mul(p.drop, (dhead + (uint64_t)(uint32_t)(i0 + r)) * (uint64_t)N + (uint64_t)rown)
+                                              : 1.f;
+                        const float d = pe * fmaf(dp[r] * dm, p.scale, -d4[r]);
+                        pt[u][r] = pe * dm;           // dV sees the dropped probabilities
                         dsv[u][r] = d;
                         dcprow[ok ? t0 + r : TLD - 1] = (__bf16)d;
                     }
@@ -684,7 +698,7 @@ bool lai_eligible(const BandParams& p, bool backward) {
         return !(e && e[0] == '0');
     }();
     if (!(enabled && p.pk != nullptr && p.dh == 64 && p.N <= 16 * LAI_MAXNT && p.w >= 0 && p.w <= LAI_MAXW &&
-          p.w <= p.N - 1 && p.drop.thresh == 0))
+          p.w <= p.N - 1))
         return false;
     return (backward ? lai_bwd_bytes(p.N, p.w) : lai_fwd_bytes(p.N, p.w)) <= 160 * 1024;     // e.g. 200+ tokens at w = 20: no
 }
@@ -706,25 +720,28 @@ void lai_launch(const BandParams& p, bool backward, hipStream_t st) {
     if (groups < 1) groups = 1;
     if (groups > p.B) groups = p.B;
     if (groups > 65535) groups = 65535;
+    const bool drop = p.drop.thresh != 0;
+#define VITK_LAI(KERN, NCV, DR)                                                                                     \
+    do {                                                                                                            \
+        (void)vitk_lds_optin((const void*)KERN<NCV, DR>, lds);                                                      \
+        hipLaunchKernelGGL((KERN<NCV, DR>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);              \
+    } while (0)
     if (!backward) {
         const size_t lds = lai_fwd_bytes(p.N, p.w);
         if (wide) {
-            (void)vitk_lds_optin((const void*)attn_fwd_lai_kernel<5>, lds);
-            hipLaunchKernelGGL((attn_fwd_lai_kernel<5>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+            if (drop) VITK_LAI(attn_fwd_lai_kernel, 5, true); else VITK_LAI(attn_fwd_lai_kernel, 5, false);
         } else {
-            (void)vitk_lds_optin((const void*)attn_fwd_lai_kernel<3>, lds);
-            hipLaunchKernelGGL((attn_fwd_lai_kernel<3>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+            if (drop) VITK_LAI(attn_fwd_lai_kernel, 3, true); else VITK_LAI(attn_fwd_lai_kernel, 3, false);
         }
         return;
     }
     const size_t lds = lai_bwd_bytes(p.N, p.w);
     if (wide) {
-        (void)vitk_lds_optin((const void*)attn_bwd_lai_kernel<5>, lds);
-        hipLaunchKernelGGL((attn_bwd_lai_kernel<5>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        if (drop) VITK_LAI(attn_bwd_lai_kernel, 5, true); else VITK_LAI(attn_bwd_lai_kernel, 5, false);
     } else {
-        (void)vitk_lds_optin((const void*)attn_bwd_lai_kernel<3>, lds);
-        hipLaunchKernelGGL((attn_bwd_lai_kernel<3>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        if (drop) VITK_LAI(attn_bwd_lai_kernel, 3, true); else VITK_LAI(attn_bwd_lai_kernel, 3, false);
     }
+#undef VITK_LAI
 }
 
 }  // namespace vitk
