@@ -240,6 +240,14 @@ int vitk_dropout(int dtype, int rows, int cols, const void* x, long ldx, const v
 int vitk_dropout_mask(long n, float p, unsigned long long seed, unsigned long long offset, unsigned char* out,
                       void* stream);
 
+/* DropPath / stochastic depth in training mode (timm_locality_aware_transformer.py:94: self.drop_path = DropPath(p),
+ * applied to both residual branches :97-98; timm 0.4.5 layers/drop.py: x / (1 - p) * floor(1 - p + rand(B, 1, 1))):
+ * y = x * keep[r / rows_per_sample] / (1 - p) [+ res] -- one decision per SAMPLE, sample s = element s of the stream
+ * (seed, offset), the same counter-based stream as vitk_dropout (vitk_dropout_mask over B elements returns the
+ * decisions).  The backward is the same call on dy (res NULL).  rows must be a whole number of samples. */
+int vitk_drop_path(int dtype, int rows, int cols, int rows_per_sample, const void* x, long ldx, const void* res, long ldr,
+                   void* y, long ldy, float p, unsigned long long seed, unsigned long long offset, void* stream);
+
 /* Label-smoothing cross entropy, mean over the batch: criterion = LabelSmoothingCrossEntropy(smoothing)
  * (train.py:273, applied :541; timm 0.4.5 loss/cross_entropy.py): (1-s) * NLL + s * mean_c(-log p).
  * logits [B, C] fp32 (row pitch ld / ld_d), target [B] int64.  fwd: loss[0] (scalar), loss_rows [B], lse [B];

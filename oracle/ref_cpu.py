@@ -69,6 +69,17 @@ def _drop(x, p):
     return x * keep.to(dtype=x.dtype, device=x.device) / (1.0 - p)
 
 
+def _drop_path(x, p):
+    """timm 0.4.5 layers/drop.py ``drop_path`` (the DropPath of timm_locality_aware_transformer.py:94; timm is a
+    third-party dependency that is not under /root/reference: published algorithm restated, parity unpinned):
+    x / (1 - p) * floor(1 - p + rand(B, 1, ..., 1)) -- one keep decision per sample, supplied like the dropout masks
+    (DROPOUT(p, (B,)))."""
+    if DROPOUT is None or p is None or p <= 0:
+        return x
+    keep = DROPOUT(float(p), (x.shape[0],)).to(dtype=x.dtype, device=x.device)
+    return x / (1.0 - p) * keep.view(-1, *([1] * (x.dim() - 1)))
+
+
 # --------------------------------------------------------------------------- A1
 class RefAttentionLAI(nn.Module):
     """timm_classes/timm_locality_aware_transformer.py:25-79."""
@@ -115,8 +126,9 @@ class RefBlockLAI(nn.Module):
     """timm_classes/timm_locality_aware_transformer.py:81-99 (pre-LN residual block)."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None,
-                 norm_layer=nn.LayerNorm, mask_epochs=None, drop=0., attn_drop=0.):
+                 norm_layer=nn.LayerNorm, mask_epochs=None, drop=0., attn_drop=0., drop_path=0.):
         super().__init__()
+        self.p_path = drop_path
         self.norm1 = norm_layer(dim)
         self.attn = RefAttentionLAI(dim, num_heads, qkv_bias, qk_scale, attn_drop=attn_drop, proj_drop=drop,
                                     mask_epochs=mask_epochs)
@@ -124,8 +136,8 @@ class RefBlockLAI(nn.Module):
         self.mlp = RefMlp(dim, int(dim * mlp_ratio), drop=drop)
 
     def forward(self, x, epoch):
-        x = x + self.attn(self.norm1(x), epoch)
-        return x + self.mlp(self.norm2(x))
+        x = x + _drop_path(self.attn(self.norm1(x), epoch), self.p_path)       # :97
+        return x + _drop_path(self.mlp(self.norm2(x)), self.p_path)            # :98
 
 
 class RefPatchEmbed(nn.Module):
@@ -152,17 +164,18 @@ class RefVisionTransformerLAI(nn.Module):
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768,
                  depth=12, num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, mask_epochs=None,
-                 drop_rate=0., attn_drop_rate=0.):
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.):
         super().__init__()
         self.p_pos = drop_rate
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]       # stochastic depth decay rule (:124)
         norm_layer = partial(nn.LayerNorm, eps=1e-6)
         self.patch_embed = RefPatchEmbed(img_size, patch_size, in_chans, embed_dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
         self.blocks = nn.ModuleList([
             RefBlockLAI(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer, mask_epochs,
-                        drop=drop_rate, attn_drop=attn_drop_rate)
-            for _ in range(depth)])
+                        drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i])
+            for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         self.head = nn.Linear(embed_dim, num_classes)
         nn.init.trunc_normal_(self.pos_embed, std=.02)

@@ -265,3 +265,71 @@ def test_graph_capture_refuses_active_dropout():
     y = torch.randint(0, 10, (4,), device='cuda')
     with pytest.raises(ValueError, match='dropout is active'):
         GraphedTrainStep(net, opt, x, y, epoch=30)
+
+
+def test_drop_path_kernel_per_sample():
+    """vitk_drop_path: one decision per sample (element s of the stream), all rows of the sample scaled by 1 / (1 - p);
+    residual folded in; the backward is the same scaling of dy."""
+    from vit_amd import ops, functional as VF, dropout as VD
+    B, N, C, p = 24, 65, 128, 0.4
+    VD.manual_seed(31)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        x = torch.randn(B * N, C, device='cuda').to(dtype).requires_grad_(True)
+        res = torch.randn(B * N, C, device='cuda').to(dtype).requires_grad_(True)
+        with VD.record() as streams:
+            y = VF.drop_path(x, p, N, res=res)
+        keep = ops.dropout_mask(B, streams[0]).float()
+        assert 0 < keep.sum().item() < B                                  # the seed gives both kinds of sample
+        mul = (keep / (1 - p)).repeat_interleave(N)[:, None]
+        assert relerr(y, x.detach().float() * mul + res.detach().float()) < tol
+        g = torch.randn_like(y)
+        y.backward(g)
+        assert relerr(x.grad, g.float() * mul) < tol and torch.equal(res.grad, g)
+    with pytest.raises(RuntimeError, match='whole number of samples'):
+        ops.dropout(torch.zeros(10, 8, device='cuda'), (0.5, 1, 0), rows_per_sample=3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_timm_lai_with_drop_path_vs_oracle(dtype):
+    """VisionTransformerLAI(drop_path_rate > 0) in training mode (reference :94,97-98,124: per-block rates from
+    linspace(0, rate, depth), a per-sample decision on each residual branch), together with attention dropout: logits and
+    every parameter gradient against the oracle fed the kernels' decisions."""
+    from oracle import ref_cpu as R
+    from vit_amd import dropout as VD
+    from vit_amd.precision import set_compute_dtype
+    from vit_amd.timm_classes.timm_locality_aware_transformer import VisionTransformerLAI
+    from vit_amd.train import label_smoothing_ce
+    me = [10, 20, 30, 40]
+    kw = dict(img_size=32, patch_size=4, num_classes=10, embed_dim=128, depth=3, num_heads=4, mlp_ratio=2.0,
+              mask_epochs=me, attn_drop_rate=0.1, drop_path_rate=0.5)
+    ref = R.RefVisionTransformerLAI(**kw)
+    sd = gi.fill_state_dict(ref.state_dict(), seed=23)
+    ref.load_state_dict(sd)
+    net = VisionTransformerLAI(**kw)
+    net.load_state_dict(sd)
+    net = set_compute_dtype(net.cuda(), dtype).train()
+    img = gi.randn(13, 'img', 8, 3, 32, 32)
+    tgt = torch.arange(8)
+    VD.manual_seed(4)
+    with VD.record() as streams:
+        out = net(img.cuda(), 15)
+    # block 0 has rate 0 (no decision drawn): 3 attention-dropout sites + 2 blocks x 2 branches
+    assert [round(s[0], 3) for s in streams] == [0.1, 0.1, 0.25, 0.25, 0.1, 0.5, 0.5], streams
+    label_smoothing_ce(out, tgt.cuda()).backward()
+    feeder = Feeder(streams)
+    R.DROPOUT = feeder
+    try:
+        out_r = ref(img, 15)
+        R.label_smoothing_ce(out_r, tgt).backward()
+    finally:
+        R.DROPOUT = None
+    assert feeder.i == len(streams)
+    f32 = dtype == torch.float32
+    assert relerr(out, out_r) < (1e-5 if f32 else 2e-2)
+    rp = dict(ref.named_parameters())
+    for n, q in net.named_parameters():
+        assert relerr(q.grad, rp[n].grad) < (5e-5 if f32 else 8e-2), n
+    net.eval()                                                            # eval: the fused one-node blocks, nothing drawn
+    with VD.record() as streams, torch.no_grad():
+        net(img.cuda(), 15)
+    assert streams == []

@@ -53,6 +53,8 @@ _SIGNATURES = {
                        c_float, c_int, c_vp, c_vp, c_long, c_vp,
                        c_vp, c_vp, c_vp, c_long, c_vp, c_vp, c_long, c_vp, c_float, c_u64, c_u64, c_vp, c_vp], c_int),
     'vitk_dropout': ([c_int, c_int, c_int, c_vp, c_long, c_vp, c_long, c_vp, c_long, c_float, c_u64, c_u64, c_vp], c_int),
+    'vitk_drop_path': ([c_int, c_int, c_int, c_int, c_vp, c_long, c_vp, c_long, c_vp, c_long, c_float, c_u64, c_u64, c_vp],
+                       c_int),
     'vitk_dropout_mask': ([c_long, c_float, c_u64, c_u64, c_vp, c_vp], c_int),
     'vitk_attn_bwd_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),
     'vitk_favor_workspace_bytes': ([c_int, c_int, c_int, c_int, c_int], c_long),

@@ -668,23 +668,26 @@ extern "C" int vitk_token_grads(int dtype, int B, int N, int D, const void* dx, 
 // y = x * keep / (1 - p) [+ res] over a [rows, cols] row view (nn.Dropout at disentangled_transformer.py:189,195,883,
 // timm_locality_aware_transformer.py:78, timm Mlp's drop, timm_vision_performer.py:61, model.py:201-203): element
 // (r, c) is element r * cols + c of the stream (seed, offset).  The backward is the same kernel on dy (no residual).
+// grp > 0: DropPath (stochastic depth, timm_locality_aware_transformer.py:94,97-98): ONE keep decision per sample, rows
+// [s * grp, (s + 1) * grp) share element s of the stream.
 namespace vitk {
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ res, long ldr,
-                                                      T* __restrict__ y, long ldy, int rows, int cols, DropParams d) {
+                                                      T* __restrict__ y, long ldy, int rows, int cols, int grp, DropParams d) {
     constexpr int V = 16 / sizeof(T);
     const int cv = cols / V;          // host guarantees cols % V == 0
     const long total = (long)rows * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int r = (int)(i / cv), c = (int)(i - (long)r * cv) * V;
         const uint64_t base = (uint64_t)r * (uint64_t)cols + (uint64_t)c;
+        const float mul_s = grp > 0 ? drop_mul(d, (uint64_t)(r / grp)) : 0.f;
         if (sizeof(T) == 2) {
             bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * ldx + c);
             bf16x8 a = {};
             if (res) a = *reinterpret_cast<const bf16x8*>(res + r * ldr + c);
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)v[e] * drop_mul(d, base + e) + (res ? (float)a[e] : 0.f));
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)v[e] * (grp > 0 ? mul_s : drop_mul(d, base + e)) + (res ? (float)a[e] : 0.f));
             *reinterpret_cast<bf16x8*>(y + r * ldy + c) = o;
         } else {
             f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, l
             if (res) a = *reinterpret_cast<const f32x4*>(res + r * ldr + c);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = v[e] * drop_mul(d, base + e) + a[e];
+            for (int e = 0; e < 4; ++e) o[e] = v[e] * (grp > 0 ? mul_s : drop_mul(d, base + e)) + a[e];
             *reinterpret_cast<f32x4*>(y + r * ldy + c) = o;
         }
     }
@@ -703,29 +706,45 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned char* __rest
 }
 }  // namespace vitk
 
-extern "C" int vitk_dropout(int dtype, int rows, int cols, const void* x, long ldx, const void* res, long ldr, void* y,
-                            long ldy, float p, unsigned long long seed, unsigned long long offset, hipStream_t stream) {
-    VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "vitk_dropout: bad dtype");
-    VITK_CHECK_ARG(rows >= 0 && cols >= 0, "vitk_dropout: negative shape");
-    VITK_CHECK_ARG(p >= 0.f && p < 1.f, "vitk_dropout: p must be in [0, 1)");
+static int dropout_launch(const char* who, int dtype, int rows, int cols, int grp, const void* x, long ldx, const void* res,
+                          long ldr, void* y, long ldy, float p, unsigned long long seed, unsigned long long offset,
+                          hipStream_t stream) {
+    VITK_CHECK_ARG(dtype == VITK_F32 || dtype == VITK_BF16, "%s: bad dtype", who);
+    VITK_CHECK_ARG(rows >= 0 && cols >= 0, "%s: negative shape", who);
+    VITK_CHECK_ARG(p >= 0.f && p < 1.f, "%s: p must be in [0, 1)", who);
     if (rows == 0 || cols == 0) return VITK_OK;
     const int esz = dtype == VITK_BF16 ? 2 : 4, V = 16 / esz;
     auto ok = [&](const void* q, long ld) {
-        return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld * esz) % 16 == 0 && ld >= cols);
+        return q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld >= cols && (ld * esz) % 16 == 0;
     };
-    VITK_CHECK_ARG(x && y && cols % V == 0 && ok(x, ldx) && ok(res, ldr) && ok(y, ldy),
-                   "vitk_dropout: rows must be 16-byte aligned, cols a multiple of %d", V);
+    VITK_CHECK_ARG(cols % V == 0 && ok(x, ldx) && ok(y, ldy) && (res == nullptr || ok(res, ldr)),
+                   "%s: rows must be 16-byte aligned, cols a multiple of %d", who, V);
     const DropParams d = vitk_drop_params(p, seed, offset);
     const long total = (long)rows * (cols / V);
     const unsigned grid = (unsigned)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     if (dtype == VITK_BF16)
         hipLaunchKernelGGL(dropout_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, (const __bf16*)x, ldx, (const __bf16*)res, ldr,
-                           (__bf16*)y, ldy, rows, cols, d);
+                           (__bf16*)y, ldy, rows, cols, grp, d);
     else
         hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, ldx, (const float*)res, ldr,
-                           (float*)y, ldy, rows, cols, d);
-    VITK_CHECK_LAUNCH("vitk_dropout");
+                           (float*)y, ldy, rows, cols, grp, d);
+    VITK_CHECK_LAUNCH(who);
     return VITK_OK;
+}
+
+extern "C" int vitk_dropout(int dtype, int rows, int cols, const void* x, long ldx, const void* res, long ldr, void* y,
+                            long ldy, float p, unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+    return dropout_launch("vitk_dropout", dtype, rows, cols, 0, x, ldx, res, ldr, y, ldy, p, seed, offset, stream);
+}
+
+// DropPath: y = x * keep[r / rows_per_sample] / (1 - p) [+ res]; sample s is element s of the stream (vitk_dropout_mask
+// over the batch gives the decisions).  The backward is the same call on dy.
+extern "C" int vitk_drop_path(int dtype, int rows, int cols, int rows_per_sample, const void* x, long ldx, const void* res,
+                              long ldr, void* y, long ldy, float p, unsigned long long seed, unsigned long long offset,
+                              hipStream_t stream) {
+    VITK_CHECK_ARG(rows_per_sample > 0 && rows % rows_per_sample == 0,
+                   "vitk_drop_path: rows (%d) must be a whole number of samples of %d rows", rows, rows_per_sample);
+    return dropout_launch("vitk_drop_path", dtype, rows, cols, rows_per_sample, x, ldx, res, ldr, y, ldy, p, seed, offset, stream);
 }
 
 // out[i] = 1 if element i of the stream (seed, offset) is kept at probability p, else 0: the mask any kernel of this

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .. import functional as VF
 from ..precision import ComputeDtypeMixin
-from ..timm_classes.timm_locality_aware_transformer import _check_p0, get_attn_mask, lai_stage_width  # noqa: F401
+from ..timm_classes.timm_locality_aware_transformer import get_attn_mask, lai_stage_width  # noqa: F401
 from .. import dropout as VD
 from ..timm_classes.timm_vision_performer import gaussian_orthogonal_random_matrix, orthogonal_matrix_chunk
 

@@ -481,15 +481,16 @@ class DropoutFn(torch.autograd.Function):
     is a function of (seed, offset, element index): the backward regenerates it, nothing is saved."""
 
     @staticmethod
-    def forward(ctx, x, drop, res):
+    def forward(ctx, x, drop, res, rows_per_sample=0):
         ctx.drop = drop
         ctx.has_res = res is not None
-        return ops.dropout(x, drop, res=res)
+        ctx.rps = rows_per_sample
+        return ops.dropout(x, drop, res=res, rows_per_sample=rows_per_sample)
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
-        return ops.dropout(dy, ctx.drop), None, (dy if ctx.has_res else None)
+        return ops.dropout(dy, ctx.drop, rows_per_sample=ctx.rps), None, (dy if ctx.has_res else None), None
 
 
 def dropout(x2d, p, res=None):
@@ -498,6 +499,16 @@ def dropout(x2d, p, res=None):
     if drop[0] == 0.0:
         return x2d if res is None else x2d + res
     return DropoutFn.apply(x2d.contiguous(), drop, res)
+
+
+def drop_path(x2d, p, rows_per_sample, res=None):
+    """DropPath / stochastic depth of a [B * rows_per_sample, C] row view (+ res): each SAMPLE's branch is kept with
+    probability 1 - p and scaled by 1 / (1 - p) (timm 0.4.5 layers/drop.py; timm_locality_aware_transformer.py:94,97-98).
+    Draws one stream; sample s is its element s."""
+    drop = VD.next_stream(p)
+    if drop[0] == 0.0:
+        return x2d if res is None else x2d + res
+    return DropoutFn.apply(x2d.contiguous(), drop, res, int(rows_per_sample))
 
 
 # --------------------------------------------------------------------------- fused encoder blocks

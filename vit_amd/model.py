@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import functional as VF
 from .precision import ComputeDtypeMixin
-from .timm_classes.timm_locality_aware_transformer import PatchEmbed, _check_p0  # noqa: F401
+from .timm_classes.timm_locality_aware_transformer import PatchEmbed
 from .timm_classes.timm_vision_performer import gaussian_orthogonal_random_matrix, orthogonal_matrix_chunk
 
 

@@ -333,9 +333,10 @@ def attn_bwd(q, k, v, B, H, N, dh, ld, pk, pq, ld_p, scale, band_w, out, dout, l
     _t1(e0, 'attn_bwd', 8.0 * B * N * H * dh * out.element_size() + 4.0 * lse.numel(), 'byte')   # q, k, v, out, dout in, dq, dk, dv out
 
 
-def dropout(x, drop, res=None, out=None):
+def dropout(x, drop, res=None, out=None, rows_per_sample=0):
     """y = x * keep / (1 - p) [+ res] on 2-D rows; drop = (p, seed, offset).  Element (r, c) is element r * cols + c of
-    the stream, so the backward is the same call on dy."""
+    the stream, so the backward is the same call on dy.  rows_per_sample > 0: DropPath -- one decision per sample
+    (rows [s * rows_per_sample, (s + 1) * rows_per_sample) share element s of the stream)."""
     _req_cuda(x, res, out)
     px, rows, cols, ldx = _rows2d(x, 'dropout x')
     if out is None:
@@ -348,6 +349,11 @@ def dropout(x, drop, res=None, out=None):
         pr, rr, cr, ldr = _rows2d(res, 'dropout res')
         if (rr, cr) != (rows, cols) or res.dtype != x.dtype:
             raise ValueError('dropout: res must match x')
+    if rows_per_sample > 0:
+        st = lib().vitk_drop_path(_dt(x), rows, cols, int(rows_per_sample), px, ldx, pr, ldr, py, ldy, float(drop[0]),
+                                  int(drop[1]), int(drop[2]), _stream())
+        check(st, 'vitk_drop_path')
+        return out
     st = lib().vitk_dropout(_dt(x), rows, cols, px, ldx, pr, ldr, py, ldy, float(drop[0]), int(drop[1]), int(drop[2]),
                             _stream())
     check(st, 'vitk_dropout')

@@ -39,15 +39,6 @@ def lai_stage_width(epoch, mask_epochs):
     return 20
 
 
-def _check_p0(module, *ps):
-    """For the one stochastic regulariser that is not built: DropPath (stochastic depth; 0 at every call site of the
-    reference's train.py).  nn.Dropout sites are implemented (vit_amd.dropout)."""
-    if module.training and any(p > 0 for p in ps):
-        raise NotImplementedError(
-            'DropPath (stochastic depth) is not implemented: the reference never sets drop_path_rate (train.py:167-194); '
-            'construct the module with drop_path_rate = 0 or call .eval()')
-
-
 class Mlp(nn.Module):
     """timm 0.4.5 Mlp: fc1 -> act -> drop -> fc2 -> drop (state_dict keys fc1.*, fc2.*)."""
 
@@ -124,7 +115,9 @@ class BlockLAI(ComputeDtypeMixin, nn.Module):
         self.norm1 = norm_layer(dim)
         self.attn = AttentionLAI(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
                                  attn_drop=attn_drop, proj_drop=drop, mask_epochs=mask_epochs)
-        self.drop_path_rate = drop_path
+        # DropPath (reference :94) has no parameters or buffers: the rate is kept, the per-sample scaling runs in
+        # forward2d (VF.drop_path) when the module trains with drop_path > 0
+        self.drop_path_rate = float(drop_path)
         self.drop_path = nn.Identity()
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
@@ -132,8 +125,18 @@ class BlockLAI(ComputeDtypeMixin, nn.Module):
     def forward2d(self, x2, B, N, epoch):
         """x2: [B*N, C] in compute dtype -> same.  The whole block is one autograd node."""
         a = self.attn
-        _check_p0(self, self.drop_path_rate)
         p_mlp = self.mlp.drop.p if self.training else 0.
+        p_path = self.drop_path_rate if self.training else 0.
+        if p_path > 0:
+            # stochastic depth (reference :94,97-98): both residual branches of a SAMPLE are dropped / rescaled as a
+            # whole, decisions drawn after the branch's own dropout sites as in the reference; separate autograd nodes
+            h = VF.layer_norm(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            br = a.forward2d(h, B, N, epoch) if isinstance(a, AttentionLAI) else a.forward2d(h, B, N)
+            x2 = VF.drop_path(br, p_path, N, res=x2)
+            h = VF.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            y = VF.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, 'gelu',
+                       p_act=p_mlp, p_out=p_mlp)
+            return VF.drop_path(y, p_path, N, res=x2)
         if not isinstance(a, AttentionLAI):      # an attention swapped in (FAVOR+, train.py:147-165)
             favor = a.favor_cfg(x2) if hasattr(a, 'favor_cfg') and FUSE_SWAPPED else None
             drops = self.training and (p_mlp > 0 or a.attn_drop.p > 0 or a.proj_drop.p > 0)

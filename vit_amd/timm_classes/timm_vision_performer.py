@@ -16,7 +16,6 @@ import torch.nn as nn
 
 from .. import functional as VF
 from ..precision import ComputeDtypeMixin
-from .timm_locality_aware_transformer import _check_p0
 
 
 def orthogonal_matrix_chunk(cols, qr_uniform_q=False, device=None):
