@@ -144,3 +144,35 @@ def test_lai_dis_kernels(B, N, H, dh, w):
     assert relerr(dpq.view(-1, H, dh), pqr.grad) < tol
     db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
     assert relerr(dbias, db_ref) < tol
+
+
+@pytest.mark.parametrize('B,N,H,dh,w', LAI_CASES)
+def test_lai_plain_kernels(B, N, H, dh, w):
+    """The same kernels without relative tables (AttentionLAI of the timm LAI ViT, reference
+    timm_classes/timm_locality_aware_transformer.py:25-79): forward, lse and dq / dk / dv / bias-gradient sums."""
+    from vit_amd import ops
+    dtype = torch.bfloat16
+    D = H * dh
+    qkv, _, _ = make(B, N, H, dh, dtype, False, seed=7 * N + w)
+    q, k, v = views(qkv, B, N, H, dh)
+    scale = dh ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), None, None, D, scale, w)
+    f = lambda t: t.double().reshape(B, N, H, dh).clone().requires_grad_(True)
+    qr, kr, vr = f(q), f(k), f(v)
+    ref, lse_ref, _ = attention_ref(qr, kr, vr, None, None, scale, w)
+    assert relerr(out.view(B, N, H, dh), ref.detach()) < 1.5e-2
+    assert relerr(lse, lse_ref.detach()) < 2e-3
+    g = torch.Generator(device='cuda').manual_seed(13)
+    dout = torch.randn(B * N, D, device='cuda', generator=g).to(dtype)
+    dqkv = torch.full_like(qkv, float('nan'))
+    dq, dk, dv = views(dqkv, B, N, H, dh)
+    dbias = torch.ones(3 * D, device='cuda')
+    ops.attn_bwd(q, k, v, B, H, N, dh, qkv.stride(0), None, None, D, scale, w, out, dout, lse,
+                 dq, dk, dv, dqkv.stride(0), None, None, dbias=dbias)
+    (ref * dout.double().view(B, N, H, dh)).sum().backward()
+    tol = 2e-2
+    assert relerr(dq.reshape(B, N, H, dh), qr.grad) < tol
+    assert relerr(dk.reshape(B, N, H, dh), kr.grad) < tol
+    assert relerr(dv.reshape(B, N, H, dh), vr.grad) < tol
+    db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
+    assert relerr(dbias, db_ref) < tol

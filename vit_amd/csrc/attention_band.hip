@@ -998,7 +998,7 @@ void lai_launch(const BandParams& p, bool backward, hipStream_t st);
 
 // Returns true when a backward launch has already produced the table gradients (p.dpk / p.dpq).
 bool band_launch(const BandParams& p, bool backward, hipStream_t st) {
-    if (lai_eligible(p, backward)) {     // banded + disentangled, one chunk, head width 64 (attention_lai.hip)
+    if (lai_eligible(p, backward)) {     // banded (with or without the disentangled tables), one chunk, head width 64 (attention_lai.hip)
         lai_launch(p, backward, st);
         return backward;
     }

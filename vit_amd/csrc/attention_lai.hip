@@ -65,14 +65,16 @@ __host__ __device__ inline LaiGeom lai_geom(int N, int w) {
     return G;
 }
 // C2P / P2C hold N rows (not NR: the 11 rows saved per array at 197 tokens are what lets both table images stay resident)
-static size_t lai_fwd_bytes(int N, int w) {
+// (without tables -- plain banded attention, AttentionLAI of timm_locality_aware_transformer.py:25-79 -- only the two row
+// images and the lse / delta rows are there)
+static size_t lai_fwd_bytes(int N, int w, bool bias) {
     const LaiGeom G = lai_geom(N, w);
-    return (size_t)2 * G.NR * LAI_ASTR * 2 + (size_t)2 * LAI_TLD * LAI_ASTR * 2 + (size_t)2 * N * LAI_LDB * 4;
+    return (size_t)2 * G.NR * LAI_ASTR * 2 + (bias ? (size_t)2 * LAI_TLD * LAI_ASTR * 2 + (size_t)2 * N * LAI_LDB * 4 : 0);
 }
-static size_t lai_bwd_bytes(int N, int w) {
+static size_t lai_bwd_bytes(int N, int w, bool bias) {
     const LaiGeom G = lai_geom(N, w);
-    return (size_t)2 * G.NR * LAI_ASTR * 2 + (size_t)G.NR * LAI_TLD * 2 + (size_t)2 * LAI_TLD * LAI_ASTR * 2 +
-           (size_t)2 * G.NR * 4 + 3 * 64 * 4 + (size_t)2 * N * LAI_LDB * 4;
+    return (size_t)2 * G.NR * LAI_ASTR * 2 + (size_t)2 * G.NR * 4 + 3 * 64 * 4 +
+           (bias ? (size_t)G.NR * LAI_TLD * 2 + (size_t)2 * LAI_TLD * LAI_ASTR * 2 + (size_t)2 * N * LAI_LDB * 4 : 0);
 }
 
 // 16 bytes of row `row` of a [nrows][ld] matrix at column d; rows outside [0, nrows) read as zero.  The load itself is
@@ -200,7 +202,8 @@ __device__ __forceinline__ uint32_t lai_mask_k(int kt, int li, int g, int N, int
 
 // grid (H, groups): the workgroup walks batch elements b = group, group + groups, ... of head h; the next element's rows
 // are requested before the current one is worked on.  NC = live tile diagonals of a row: 3 (w <= 16) or 5.
-template <int NC, bool DROP>
+// BIAS = false: no relative tables (plain banded attention): the same kernel without C2P / P2C.
+template <int NC, bool DROP, bool BIAS>
 __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandParams p, int groups) {
     using T = __bf16;
     constexpr int ASTR = LAI_ASTR, LDB = LAI_LDB, CM = (NC - 1) / 2, NP = (NC + 1) / 2;
@@ -235,14 +238,14 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
     // per-lane constants of the loop below
     const int rowb = li * ASTR + 8 * g, colb = (4 * g + (li >> 2)) * ASTR + 4 * (li & 3);
     const int T0 = li - 4 * g - 16 * CM + w;
-    const float* pc = C2P + qin * LDB + T0 - 3;
+    const float* pc = C2P + qin * LDB + T0 - 3;                  // (BIAS only: never dereferenced without tables)
     const float* pp = P2C + (16 * (qt - CM) + 4 * g) * LDB + T0 + 16 * (NC - 1);
     const uint32_t okm = own ? lai_mask_q<NC>(qt, li, g, N, G.NT, w) : 0u;
     int ktc[NC];
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) ktc[ci] = min(max(qt + CM - ci, 0), G.NT - 1);
 
-    lai_stage_tables(tabk, tabq, PK, PQ, p.ld_p, N - 1 - w, G.TW, 2 * N - 1, tid);
+    if (BIAS) lai_stage_tables(tabk, tabq, PK, PQ, p.ld_p, N - 1 - w, G.TW, 2 * N - 1, tid);
     Frag<T> nq[2], nk[2], nv[2];
     {
         const long o = (long)blockIdx.y * hb;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
             qf[1] = nq[1];
             lai_put_rows(Ks, nk, qi, lane);
             lai_put_rows(Vs, nv, qi, lane);
-            lai_bias_rows(tabk, tabq, G, qf, nk, C2P + qin * LDB, P2C + qin * LDB, qi < N, lane);
+            if (BIAS) lai_bias_rows(tabk, tabq, G, qf, nk, C2P + qin * LDB, P2C + qin * LDB, qi < N, lane);
         }
         auto prefetch = [&]() {   // the next batch element's rows (the last one asks for its own again: no branch around the loads)
             const long o = (long)min(b + groups, p.B - 1) * hb;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = (s[r] + pc[16 * ci + 3 - r] + pp[(NC - 1 - ci) * (16 * LDB - 16) + r * (LDB - 1)]) * sc2;
+                    const float v = (BIAS ? s[r] + pc[16 * ci + 3 - r] + pp[(NC - 1 - ci) * (16 * LDB - 16) + r * (LDB - 1)] : s[r]) * sc2;
                     sc[ci][r] = (okm >> (4 * ci + r)) & 1u ? v : -INFINITY;
                     m = fmaxf(m, sc[ci][r]);
                 }
@@ -396,7 +399,7 @@ __device__ __forceinline__ f32x4 lai_table_grad(f32x4 acc, const __bf16* dcp, co
 }
 
 // grid (H, groups): the workgroup walks batch elements b = group, group + groups, ... of head h.
-template <int NC, bool DROP>
+template <int NC, bool DROP, bool BIAS>
 __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandParams p, int groups) {
     using T = __bf16;
     constexpr int ASTR = LAI_ASTR, TLD = LAI_TLD, CM = (NC - 1) / 2, NP = (NC + 1) / 2;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
     float* P2C = reinterpret_cast<float*>(tabq + TLD * ASTR);    // [N][LDB]
     float* C2P = P2C + N * LDB;
     T* dcp = reinterpret_cast<T*>(C2P + N * LDB);         // dC2P, then dP2C: [NR][48]  (2 N LDB floats: a multiple of 16 bytes)
-    float* lse2s = reinterpret_cast<float*>(dcp + NR * TLD);
+    float* lse2s = BIAS ? reinterpret_cast<float*>(dcp + NR * TLD) : reinterpret_cast<float*>(tabk);   // (no tables: behind the images)
     float* dls = lse2s + NR;
     float* colacc = dls + NR;                             // [3][64]: column sums of dQ | dK | dV over this workgroup's heads
 
@@ -428,11 +431,11 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
     const bool own = wave < G.NT;
-    const bool tgw = wave < 4 * NDT;                      // owns one tile of each table gradient
+    const bool tgw = BIAS && wave < 4 * NDT;              // owns one tile of each table gradient
     const int tg_u = wave >> 2, tg_dt = wave & 3;
     f32x4 apk = {0.f, 0.f, 0.f, 0.f}, apq = {0.f, 0.f, 0.f, 0.f};
     if (tid < 3 * 64) colacc[tid] = 0.f;
-    lai_stage_tables(tabk, tabq, PK, PQ, p.ld_p, tab_r0, G.TW, 2 * N - 1, tid);
+    if (BIAS) lai_stage_tables(tabk, tabq, PK, PQ, p.ld_p, tab_r0, G.TW, 2 * N - 1, tid);
     lai_barrier();
 
     for (int b = blockIdx.y; b < p.B; b += groups) {
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
             if (own) {
                 lai_put_rows(img0, kfo, row, lane);
                 lai_put_rows(img1, vfo, row, lane);
-                lai_bias_rows(tabk, tabq, G, qf, kfo, C2P + rown * LDB, P2C + rown * LDB, row < N, lane);
+                if (BIAS) lai_bias_rows(tabk, tabq, G, qf, kfo, C2P + rown * LDB, P2C + rown * LDB, row < N, lane);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -479,8 +482,9 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                     lse2s[row] = l2;
                     dls[row] = dlt * p.scale;             // pre-scaled: dS = P (dP scale - delta scale)
                 }
-                for (int i = lane; i < 16 * TLD * 2 / 16; i += 64)   // own dC2P rows: zero (entries outside [0, N) stay so)
-                    reinterpret_cast<u32x4*>(dcp + 16 * wave * TLD)[i] = u32x4{0, 0, 0, 0};
+                if (BIAS)
+                    for (int i = lane; i < 16 * TLD * 2 / 16; i += 64)   // own dC2P rows: zero (entries outside [0, N) stay so)
+                        reinterpret_cast<u32x4*>(dcp + 16 * wave * TLD)[i] = u32x4{0, 0, 0, 0};
             }
         }
         lai_barrier();
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = (unsigned)(t0 - r) < (unsigned)G.TW && (unsigned)(j0 + r) < (unsigned)N;
-                        const float raw = s[r] + pc[3 - r] + pp[r * (LDB - 1)];
+                        const float raw = BIAS ? s[r] + pc[3 - r] + pp[r * (LDB - 1)] : s[r];
                         const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(raw, sc2, -l2) : -INFINITY);
                         // dropout: dP = (dO V^T) * keep / (1 - p); delta is unchanged (O was made from the dropped P)
                         const float dm = DROP ? drop_mul(p.drop, (dhead + (uint64_t)rown) * (uint64_t)N + (uint64_t)(uint32_t)(j0 + r))
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                         const float d = pe * fmaf(dp[r] * dm, p.scale, -dls_own);
                         dsv[u][r] = d;
                         // outside the band d = 0: written to a pad column (47) of the own row instead of branching
-                        dcprow[ok ? t0 - r : TLD - 1] = (__bf16)d;
+                        if (BIAS) dcprow[ok ? t0 - r : TLD - 1] = (__bf16)d;
                     }
                 }
                 Frag<T> bs;
@@ -548,8 +552,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                     dq[dt] = mma(a, bs, dq[dt]);
                 }
             }
-            wave_lds_sync();
-            lai_table_product(dq, tabk, dcprow, KBT, lane);         // dQ_i += sum_t dC2P[i][t] Pk_b[t]
+            if (BIAS) {
+                wave_lds_sync();
+                lai_table_product(dq, tabk, dcprow, KBT, lane);     // dQ_i += sum_t dC2P[i][t] Pk_b[t]
+            }
             if (row < N) {
                 T* dQ = reinterpret_cast<T*>(p.dq) + ((long)b * N + row) * p.ld_d + h * 64;
 #pragma unroll
@@ -571,8 +577,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
             lai_put_rows(img1, dof, row, lane);
         }
         lai_barrier();
-        if (tgw) apk = lai_table_grad(apk, dcp, img0, NR, tg_u, tg_dt, lane);
-        lai_barrier();
+        if (BIAS) {
+            if (tgw) apk = lai_table_grad(apk, dcp, img0, NR, tg_u, tg_dt, lane);
+            lai_barrier();
+        }
         if (VITK_LAI_STOP == 4) continue;
 
         // ---- phase C: key-stationary (lane = key `row`): P and dS again, dK, dV, dP2C --------------------------
@@ -582,8 +590,9 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
             const float* ppC = P2C + rown * LDB + (4 * g - li - 16 * CM + w);
             const float* pcC = C2P + (16 * (kt - CM) + 4 * g) * LDB + (4 * g - li - 16 * CM + w);
             T* dcprow = dcp + row * TLD;
-            for (int i = lane; i < 16 * TLD * 2 / 16; i += 64)
-                reinterpret_cast<u32x4*>(dcp + 16 * wave * TLD)[i] = u32x4{0, 0, 0, 0};
+            if (BIAS)
+                for (int i = lane; i < 16 * TLD * 2 / 16; i += 64)
+                    reinterpret_cast<u32x4*>(dcp + 16 * wave * TLD)[i] = u32x4{0, 0, 0, 0};
             f32x4 dk[4], dv[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -622,14 +631,14 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = (unsigned)(t0 + r) < (unsigned)G.TW && (unsigned)(i0 + r) < (unsigned)N;
-                        const float raw = s[r] + pc[r * (LDB + 1)] + pp[r];
+                        const float raw = BIAS ? s[r] + pc[r * (LDB + 1)] + pp[r] : s[r];
                         const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(raw, sc2, -l4[r]) : -INFINITY);
                         const float dm = DROP ? drop_mul(p.drop, (dhead + (uint64_t)(uint32_t)(i0 + r)) * (uint64_t)N + (uint64_t)rown)
                                               : 1.f;
                         const float d = pe * fmaf(dp[r] * dm, p.scale, -d4[r]);
                         pt[u][r] = pe * dm;           // dV sees the dropped probabilities
                         dsv[u][r] = d;
-                        dcprow[ok ? t0 + r : TLD - 1] = (__bf16)d;
+                        if (BIAS) dcprow[ok ? t0 + r : TLD - 1] = (__bf16)d;
                     }
                 }
                 Frag<T> bp, bs;
@@ -644,8 +653,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
                     dk[dt] = mma(a, bs, dk[dt]);          // dK^T[d][key] += Q^T[d][q] dS[q][key]
                 }
             }
-            wave_lds_sync();
-            lai_table_product(dk, tabq, dcprow, KBT, lane);         // dK_j += sum_t dP2C[j][t] Pq_b[t]
+            if (BIAS) {
+                wave_lds_sync();
+                lai_table_product(dk, tabq, dcprow, KBT, lane);     // dK_j += sum_t dP2C[j][t] Pq_b[t]
+            }
             if (row < N) {
                 T* dK = reinterpret_cast<T*>(p.dk) + ((long)b * N + row) * p.ld_d + h * 64;
                 T* dV = reinterpret_cast<T*>(p.dv) + ((long)b * N + row) * p.ld_d + h * 64;
@@ -666,10 +677,12 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_lai_kernel(const BandPar
         if (VITK_LAI_STOP == 5) continue;
 
         // ---- K again (from the registers); dPq_b += dP2C^T K ------------------------------------------------------
-        if (own) lai_put_rows(img0, kfo, row, lane);
-        lai_barrier();
-        if (tgw) apq = lai_table_grad(apq, dcp, img0, NR, tg_u, tg_dt, lane);
-        lai_barrier();
+        if (BIAS) {
+            if (own) lai_put_rows(img0, kfo, row, lane);
+            lai_barrier();
+            if (tgw) apq = lai_table_grad(apq, dcp, img0, NR, tg_u, tg_dt, lane);
+            lai_barrier();
+        }
     }
 
     // ---- flush: table gradients (one 16 x 16 tile of each per wave), bias-gradient column sums -------------------
@@ -697,10 +710,9 @@ bool lai_eligible(const BandParams& p, bool backward) {
         const char* e = getenv("VITK_ATTN_LAI");
         return !(e && e[0] == '0');
     }();
-    if (!(enabled && p.pk != nullptr && p.dh == 64 && p.N <= 16 * LAI_MAXNT && p.w >= 0 && p.w <= LAI_MAXW &&
-          p.w <= p.N - 1))
-        return false;
-    return (backward ? lai_bwd_bytes(p.N, p.w) : lai_fwd_bytes(p.N, p.w)) <= 160 * 1024;     // e.g. 200+ tokens at w = 20: no
+    if (!(enabled && p.dh == 64 && p.N <= 16 * LAI_MAXNT && p.w >= 0 && p.w <= LAI_MAXW && p.w <= p.N - 1)) return false;
+    const bool bias = p.pk != nullptr;
+    return (backward ? lai_bwd_bytes(p.N, p.w, bias) : lai_fwd_bytes(p.N, p.w, bias)) <= 160 * 1024;     // e.g. 200+ tokens at w = 20: no
 }
 static_assert(2 * 208 * LAI_ASTR * 2 + 208 * LAI_TLD * 2 + 2 * LAI_TLD * LAI_ASTR * 2 + 2 * 208 * 4 + 768 + 2 * 197 * LAI_LDB * 4 <=
                   160 * 1024, "backward at 197 tokens, w = 20");
@@ -721,13 +733,18 @@ void lai_launch(const BandParams& p, bool backward, hipStream_t st) {
     if (groups > p.B) groups = p.B;
     if (groups > 65535) groups = 65535;
     const bool drop = p.drop.thresh != 0;
+    const bool bias = p.pk != nullptr;
+#define VITK_LAI2(KERN, NCV, DR, BI)                                                                                \
+    do {                                                                                                            \
+        (void)vitk_lds_optin((const void*)KERN<NCV, DR, BI>, lds);                                                  \
+        hipLaunchKernelGGL((KERN<NCV, DR, BI>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);          \
+    } while (0)
 #define VITK_LAI(KERN, NCV, DR)                                                                                     \
     do {                                                                                                            \
-        (void)vitk_lds_optin((const void*)KERN<NCV, DR>, lds);                                                      \
-        hipLaunchKernelGGL((KERN<NCV, DR>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);              \
+        if (bias) VITK_LAI2(KERN, NCV, DR, true); else VITK_LAI2(KERN, NCV, DR, false);                             \
     } while (0)
     if (!backward) {
-        const size_t lds = lai_fwd_bytes(p.N, p.w);
+        const size_t lds = lai_fwd_bytes(p.N, p.w, bias);
         if (wide) {
             if (drop) VITK_LAI(attn_fwd_lai_kernel, 5, true); else VITK_LAI(attn_fwd_lai_kernel, 5, false);
         } else {
@@ -735,13 +752,14 @@ void lai_launch(const BandParams& p, bool backward, hipStream_t st) {
         }
         return;
     }
-    const size_t lds = lai_bwd_bytes(p.N, p.w);
+    const size_t lds = lai_bwd_bytes(p.N, p.w, bias);
     if (wide) {
         if (drop) VITK_LAI(attn_bwd_lai_kernel, 5, true); else VITK_LAI(attn_bwd_lai_kernel, 5, false);
     } else {
         if (drop) VITK_LAI(attn_bwd_lai_kernel, 3, true); else VITK_LAI(attn_bwd_lai_kernel, 3, false);
     }
 #undef VITK_LAI
+#undef VITK_LAI2
 }
 
 }  // namespace vitk
