@@ -176,3 +176,22 @@ def test_lai_plain_kernels(B, N, H, dh, w):
     assert relerr(dv.reshape(B, N, H, dh), vr.grad) < tol
     db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
     assert relerr(dbias, db_ref) < tol
+
+
+@pytest.mark.parametrize('B,N,H,dh', [(2, 197, 2, 64), (1, 201, 3, 64), (3, 130, 2, 64), (20, 150, 16, 64), (128, 197, 16, 64)])
+def test_full_dis_forward(B, N, H, dh):
+    """Unmasked disentangled forward on the per-head kernel (whole score rows in registers, position terms summed into one
+    bf16 array per head): output and lse against fp64 (the last case is BASELINE.json's full shape)."""
+    from vit_amd import ops
+    dtype = torch.bfloat16
+    D = H * dh
+    qkv, pk, pq = make(B, N, H, dh, dtype, True, seed=3 * N + 1)
+    q, k, v = views(qkv, B, N, H, dh)
+    scale = (dh * 3) ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, -1)
+    f = lambda t: t.double().reshape(B, N, H, dh)
+    ref, lse_ref, _ = attention_ref(f(q), f(k), f(v), pk.double().view(-1, H, dh), pq.double().view(-1, H, dh), scale, -1)
+    assert relerr(out.view(B, N, H, dh), ref) < 1.5e-2
+    assert relerr(lse, lse_ref) < 2e-3
+    out2, lse2 = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, N - 1)     # a band that masks nothing
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)

@@ -349,6 +349,271 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
     }
 }
 
+// ---------------------------------------------------------------------------- forward, unmasked stage
+// The whole head without a band (w < 0: config 3, and the last LAI stage of every DisLAI run): every query sees all N
+// keys and all 2N-1 relative rows are live.  Same ownership as above (wave = query tile, lane = query, a workgroup walks the
+// batch elements of one head), but
+//   * a whole score ROW lives in registers: 13 tiles x 4 scores per lane, one softmax, no online rescaling;
+//   * the two position terms are summed ONCE per head into one bf16 array  Bias[i][j] = C2P[i][i-j] + P2C[j][i-j]
+//     ([N][212], 83.5 KiB at 197 tokens) that the score loop reads with ONE 8-byte LDS load per tile and lane.
+// Bias is made on the matrix cores in strips: query tile qt needs the table rows t = i - j + N - 1 in [16 qt, 16 qt + N + 14]
+// -- 14 ALIGNED 16-row table tiles -- and key tile kt a 14-tile strip of the other table; X^T[t][i] = Pk[t] . Q_i (lane =
+// query i, registers = 4 consecutive t) is scattered to Bias[i][i - t + N - 1] as four 2-byte LDS stores, then, after a
+// barrier, Y^T[t][j] = Pq[t] . K_j is added at Bias[t + j - N + 1][j] (each element has exactly one writer per phase).
+// The tables do not fit beside it (2 x 56 KiB): their tiles pass through two 4-tile buffers, 7 rounds per table, every wave
+// taking the tiles of its strip as they come by (one workgroup barrier per round; the next round's rows are in flight
+// from L2 meanwhile).  attention_band.hip forms the same products per 16 x 16 tile PAIR (8 MFMAs, 4 LDS stores, 8 LDS
+// loads and two intra-wave hand-offs per pair): 264 us per layer at the headline shape against 209 here -- of which the Bias
+// strips are 100 (their 2-byte scatter / read-modify-write LDS traffic, 2184 wave instructions per head, not the MFMAs),
+// the score loop + P V 85, row loads, staging and the 16 barriers 40 (tools/lai_phases.sh with VITK_STOP_MACRO=VITK_FULL_STOP).
+// Balancing the rounds and dropping the range tests of interior tiles changed nothing: the strips are bound by the
+// latency chain load - MFMA - MFMA - convert - (load - add) - store of each tile with four waves per SIMD.
+#ifndef VITK_FULL_STOP
+#define VITK_FULL_STOP 0             // timing experiments (tools/lai_phases.sh): bit 0 skips the Bias products, bit 1 the score loop, bit 2 P V
+#endif
+constexpr int FULL_LDJ = 212;                  // Bias row: 13 x 16 key columns + pad (8-byte aligned rows, odd multiple of 4 banks)
+constexpr int FULL_TPR = 4;                    // table tiles per round
+constexpr int FULL_TBUF = FULL_TPR * 16 * LAI_ASTR;      // elements of one table buffer
+static size_t full_fwd_bytes(int N) {
+    const LaiGeom G = lai_geom(N, 0);
+    return (size_t)2 * G.NR * LAI_ASTR * 2 + (size_t)2 * FULL_TBUF * 2 + (size_t)N * FULL_LDJ * 2;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandParams p, int groups) {
+    using T = __bf16;
+    constexpr int ASTR = LAI_ASTR, LDJ = FULL_LDJ, NTC = LAI_MAXNT, NP = (NTC + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int N = p.N;
+    const LaiGeom G = lai_geom(N, 0);
+    const int NT = G.NT;
+    const int h = blockIdx.x;
+
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vs = Ks + G.NR * ASTR;
+    T* tbuf = Vs + G.NR * ASTR;                     // two table buffers
+    T* Bias = tbuf + 2 * FULL_TBUF;                 // [N][LDJ]
+
+    const T* PK = reinterpret_cast<const T*>(p.pk) + h * 64;
+    const T* PQ = reinterpret_cast<const T*>(p.pq) + h * 64;
+    const long hb = (long)N * p.ld;
+    const T* Qh = reinterpret_cast<const T*>(p.q) + h * 64;
+    const T* Kh = reinterpret_cast<const T*>(p.k) + h * 64;
+    const T* Vh = reinterpret_cast<const T*>(p.v) + h * 64;
+
+    const int qt = wave;                             // query tile AND key tile this wave owns
+    const bool own = qt < NT;
+    const int qi = 16 * qt + li;
+    const int fr = own ? qi : -1;
+    const int qin = min(qi, N - 1);
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const int rowb = li * ASTR + 8 * g, colb = (4 * g + (li >> 2)) * ASTR + 4 * (li & 3);
+    const int R = 2 * N - 1;                         // table rows
+    constexpr int NRND = (2 * LAI_MAXNT + FULL_TPR - 1) / FULL_TPR;      // 7 rounds per table (tiles past the table: zero rows)
+    // table tiles of this wave's strips: t = i - j + N - 1 over its 16 queries and all keys / its 16 keys and all queries
+    const int lo_q = qt, hi_q = (16 * qt + 14 + N) >> 4;
+    const int lo_k = max(0, N - 16 - 16 * qt) >> 4, hi_k = max(0, 2 * N - 2 - 16 * qt) >> 4;
+    // Staging: a round's 4 x 16 table rows are 512 pieces of 16 bytes.  Waves 0-7 carry the even rounds, waves 8-15 the odd
+    // ones; a thread's seven pieces of a head are the SAME for every batch element, so it walks them as a cycle and keeps
+    // the next FOUR in flight / in registers at all times (also through the score loop): a round never waits for L2 -- with
+    // one round in flight every round took a memory round trip (21 of a head's 30 us).
+    const int grp = wave >> 3;
+    const int st_row = (tid & 511) >> 3, st_d = (tid & 7) * 8;   // row 0..63 of the round, column
+    auto table_piece = [&](int k) -> u32x4 {                     // piece k of this thread: round 2k + grp
+        const int rnd = 2 * k + grp;                             // rounds 0 .. NRND-1: Pk, NRND .. 2 NRND-1: Pq
+        const bool second = rnd >= NRND;
+        // round rho of a table carries its tiles rho, rho + 7, rho + 14, rho + 21: every 14-tile strip has exactly two
+        // of them, so every wave has two tiles of work in every round (with four CONSECUTIVE tiles per round the middle
+        // rounds had all waves on four tiles and the outer ones almost none: 49 against 3 wave-tiles)
+        const int r0 = 16 * ((second ? rnd - NRND : rnd) + NRND * (st_row >> 4)) + (st_row & 15);
+        return lai_load16(second ? PQ : PK, p.ld_p, r0, R, st_d);
+    };
+    T* const st_dst = tbuf + grp * FULL_TBUF + st_row * ASTR + st_d;      // even rounds -> buffer 0, odd rounds -> buffer 1
+
+    Frag<T> nq[2], nk[2], nv[2];
+    {
+        const long o = (long)blockIdx.y * hb;
+        lai_row_frags(nq, Qh + o, p.ld, fr, N, lane);
+        lai_row_frags(nk, Kh + o, p.ld, fr, N, lane);
+        lai_row_frags(nv, Vh + o, p.ld, fr, N, lane);
+    }
+    u32x4 q0 = table_piece(0), q1 = table_piece(1), q2 = table_piece(2), q3 = table_piece(3);
+    int knext = 4;               // the piece asked for next
+    auto stage_next = [&]() {    // this thread's next piece -> its buffer; ask for the one four ahead
+        *reinterpret_cast<u32x4*>(st_dst) = q0;
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
+        q3 = table_piece(knext);
+        knext = knext == NRND - 1 ? 0 : knext + 1;
+    };
+
+    for (int b = blockIdx.y; b < p.B; b += groups) {
+        Frag<T> qf[2], kf[2];
+        qf[0] = nq[0];
+        qf[1] = nq[1];
+        kf[0] = nk[0];
+        kf[1] = nk[1];
+        if (own) {
+            lai_put_rows(Ks, nk, qi, lane);
+            lai_put_rows(Vs, nv, qi, lane);
+        }
+        if (grp == 0) stage_next();                  // round 0 -> buffer 0
+        lai_barrier();
+        // ---- Bias: 2 NRND rounds of 4 table tiles ---------------------------------------------------------------
+        // per-lane bases; every element of a round is at a compile-time offset from them.  A query / key past the sequence
+        // gets a poisoned index: none of its range tests passes, and its writes go to a pad column of its own row
+        const int jb = qi < N ? qi + N - 1 - 4 * g : -(1 << 20);           // j of (tt = 0, r = 0)
+        const int ib = qi < N ? qi - (N - 1) + 4 * g : -(1 << 20);         // i of (tt = 0, r = 0)
+        T* const c2p_b = Bias + qin * LDJ + (qin + N - 1 - 4 * g) - 3;     // &Bias[i][j of (tt = 0, r = 3)]
+        T* const p2c_b = Bias + (qin - (N - 1) + 4 * g) * LDJ + qin;       // &Bias[i of (tt = 0, r = 0)][j]
+        T* const padp = Bias + qin * LDJ + 16 * LAI_MAXNT + g;
+        auto bias_round = [&](int rnd, const T* tb) {
+            if (!own || (VITK_FULL_STOP & 1)) return;
+            const bool second = rnd >= NRND;
+            const int rho = second ? rnd - NRND : rnd;           // tiles rho + 7 u
+            if (!second) {
+                T* cb = c2p_b - 16 * rho;
+                const int j0 = jb - 16 * rho;
+#pragma unroll
+                for (int u = 0; u < FULL_TPR; ++u) {
+                    const int tt = rho + NRND * u;
+                    if (tt < lo_q || tt > hi_q) continue;        // wave-uniform
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        Frag<T> a;
+                        frag_load(a, tb + u * (16 * ASTR) + rowb + 32 * kb);
+                        x = mma(a, qf[kb], x);           // X^T[t = 16 tt + 4g + r][query li]: Bias[i][i - t + N - 1] = C2P
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        T* e = (unsigned)(j0 - 16 * NRND * u - r) < (unsigned)N ? cb + (3 - r - 16 * NRND * u) : padp;
+                        *e = (T)x[r];
+                    }
+                }
+            } else {
+                T* pb = p2c_b + 16 * rho * LDJ;
+                const int i0 = ib + 16 * rho;
+#pragma unroll
+                for (int u = 0; u < FULL_TPR; ++u) {
+                    const int tt = rho + NRND * u;
+                    if (tt < lo_k || tt > hi_k) continue;
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        Frag<T> a;
+                        frag_load(a, tb + u * (16 * ASTR) + rowb + 32 * kb);
+                        x = mma(a, kf[kb], x);           // Y^T[t][key li]: Bias[t + j - N + 1][j] += P2C
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        T* e = (unsigned)(i0 + 16 * NRND * u + r) < (unsigned)N ? pb + (16 * NRND * u + r) * LDJ : padp;
+                        *e = (T)((float)*e + x[r]);
+                    }
+                }
+            }
+        };
+#pragma nounroll
+        for (int it = 0; it < NRND; ++it) {
+            bias_round(2 * it, tbuf);
+            if (grp == 1) stage_next();                          // round 2 it + 1 -> buffer 1 (last read in round 2 it - 1)
+            lai_barrier();
+            bias_round(2 * it + 1, tbuf + FULL_TBUF);
+            if (grp == 0 && it + 1 < NRND) stage_next();         // round 2 it + 2 -> buffer 0
+            lai_barrier();
+        }
+        // ---- scores of the whole row, softmax, P V -----------------------------------------------------------------
+        if (own && !(VITK_FULL_STOP & 2)) {
+            const uint64_t dhead = (uint64_t)(b * p.H + h) * (uint64_t)N;
+            const T* brow = Bias + qin * LDJ + 4 * g;
+            f32x4 sc[NTC];
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NTC; ++kt) {
+                const int ktc = min(kt, NT - 1);
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    Frag<T> kr;
+                    lai_rfrag(kr, Ks, rowb, ktc, kb);
+                    s = mma(kr, qf[kb], s);          // raw[query li][key 16 kt + 4g + r]
+                }
+                const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(brow + 16 * kt);
+                if (16 * kt + 16 <= N) {             // (scalar branch) a tile inside the sequence: no mask
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[kt][r] = (s[r] + (float)b4[r]) * sc2;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sc[kt][r] = 16 * kt + 4 * g + r < N ? (s[r] + (float)b4[r]) * sc2 : -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float ls = 0.f;
+            const uint64_t drow = DROP ? (dhead + (uint64_t)qin) * (uint64_t)N : 0;
+#pragma unroll
+            for (int kt = 0; kt < NTC; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sc[kt][r] - m);
+                    ls += pv;
+                    sc[kt][r] = DROP ? pv * drop_mul(p.drop, drow + (uint64_t)(uint32_t)min(16 * kt + 4 * g + r, N - 1)) : pv;
+                }
+                if (DROP) __builtin_amdgcn_sched_barrier(0);
+            }
+            ls += __shfl_xor(ls, 16, 64);
+            ls += __shfl_xor(ls, 32, 64);
+            f32x4 oacc[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (VITK_FULL_STOP & 4) {
+#pragma unroll
+                for (int kt = 0; kt < NTC; ++kt) oacc[kt & 3] += sc[kt];
+            } else
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) {
+                constexpr f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                const int ca = 2 * pi, cb = 2 * pi + 1 < NTC ? 2 * pi + 1 : 2 * pi;
+                Frag<T> pf;
+                acc_to_frag(pf, sc[ca], 2 * pi + 1 < NTC ? sc[cb] : zero4);
+                const int ka = min(ca, NT - 1), kb2 = min(cb, NT - 1);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Frag<T> vf;
+                    lai_cfrag(vf, Vs, colb, ka, kb2, dt);
+                    oacc[dt] = mma(vf, pf, oacc[dt]);     // O^T[d = 16 dt + 4g + r][query li]
+                }
+            }
+            // the next element's rows: asked for once the score registers are free
+            {
+                const long o = (long)min(b + groups, p.B - 1) * hb;
+                lai_row_frags(nq, Qh + o, p.ld, fr, N, lane);
+                lai_row_frags(nk, Kh + o, p.ld, fr, N, lane);
+                lai_row_frags(nv, Vh + o, p.ld, fr, N, lane);
+            }
+            if (qi < N) {
+                const float inv = __builtin_amdgcn_rcpf(ls);
+                T* O = reinterpret_cast<T*>(p.out) + ((long)b * N + qi) * p.ldo + h * 64;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<bf16x4*>(O + 16 * dt + 4 * g) =
+                        bf16x4{(__bf16)(oacc[dt][0] * inv), (__bf16)(oacc[dt][1] * inv), (__bf16)(oacc[dt][2] * inv),
+                               (__bf16)(oacc[dt][3] * inv)};
+                if (g == 0)
+                    p.lse[((long)b * p.H + h) * N + qi] = (m + __builtin_amdgcn_logf(ls)) * 0.6931471805599453f;
+            }
+        }
+        lai_barrier();            // everybody is done with the images before the next element's rows land in them
+    }
+}
+
 // ----------------------------------------------------------------------------------------- backward
 // column sums of a [64 d][16 rows] accumulator set over its 16 row lanes, += dst[d] (LDS)
 __device__ __forceinline__ void lai_colsum(const f32x4 (&acc)[4], float* dst, int g, int li) {
@@ -716,6 +981,28 @@ bool lai_eligible(const BandParams& p, bool backward) {
 }
 static_assert(2 * 208 * LAI_ASTR * 2 + 208 * LAI_TLD * 2 + 2 * LAI_TLD * LAI_ASTR * 2 + 2 * 208 * 4 + 768 + 2 * 197 * LAI_LDB * 4 <=
                   160 * 1024, "backward at 197 tokens, w = 20");
+
+// unmasked stage, forward: heads of 64 with tables, one chunk, and the Bias array must fit beside the images
+bool full_eligible(const BandParams& p, bool backward) {
+    static const bool enabled = [] {
+        const char* e = getenv("VITK_ATTN_FULL");
+        return !(e && e[0] == '0');
+    }();
+    // (short heads: the 13 score tiles a lane carries would be mostly padding; dropout on the probabilities: the mask
+    // hashes beside 52 score registers spill -- both stay on attention_band.hip)
+    if (backward || !enabled || p.pk == nullptr || p.dh != 64 || p.N > 16 * LAI_MAXNT || p.N <= 128) return false;
+    if (p.drop.thresh != 0 || (p.w >= 0 && p.w < p.N - 1)) return false;
+    return full_fwd_bytes(p.N) <= 160 * 1024;          // up to 201 tokens
+}
+void full_launch(const BandParams& p, hipStream_t st) {
+    int groups = 256 / p.H;
+    if (groups < 1) groups = 1;
+    if (groups > p.B) groups = p.B;
+    if (groups > 65535) groups = 65535;
+    const size_t lds = full_fwd_bytes(p.N);
+    (void)vitk_lds_optin((const void*)attn_fwd_full_kernel<false>, lds);
+    hipLaunchKernelGGL((attn_fwd_full_kernel<false>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+}
 
 void lai_launch(const BandParams& p, bool backward, hipStream_t st) {
     const bool wide = p.w > 16;
