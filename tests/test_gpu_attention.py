@@ -195,3 +195,40 @@ def test_full_dis_forward(B, N, H, dh):
     assert relerr(lse, lse_ref) < 2e-3
     out2, lse2 = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, N - 1)     # a band that masks nothing
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
+
+
+@pytest.mark.parametrize('B,N,H,dh', [(2, 197, 2, 64), (1, 200, 3, 64), (1, 201, 3, 64), (3, 130, 2, 64), (2, 144, 2, 64), (20, 150, 16, 64),
+                                      (128, 197, 16, 64)])        # (201 tokens: forward on the new kernel, backward on attention_band.hip)
+def test_full_dis_backward(B, N, H, dh):
+    """... and its backward (Bias / P / dS in one LDS array; table gradients from the dS tiles it leaves): dq, dk, dv, both
+    table gradients and the q/k/v bias sums against fp64 autograd."""
+    from vit_amd import ops
+    dtype = torch.bfloat16
+    D = H * dh
+    qkv, pk, pq = make(B, N, H, dh, dtype, True, seed=3 * N + 2)
+    q, k, v = views(qkv, B, N, H, dh)
+    scale = (dh * 3) ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, -1)
+    f = lambda t: t.double().reshape(B, N, H, dh).clone().requires_grad_(True)
+    qr, kr, vr = f(q), f(k), f(v)
+    pkr = pk.double().view(-1, H, dh).clone().requires_grad_(True)
+    pqr = pq.double().view(-1, H, dh).clone().requires_grad_(True)
+    ref, _, _ = attention_ref(qr, kr, vr, pkr, pqr, scale, -1)
+    g = torch.Generator(device='cuda').manual_seed(17)
+    dout = torch.randn(B * N, D, device='cuda', generator=g).to(dtype)
+    dqkv = torch.full_like(qkv, float('nan'))
+    dq, dk, dv = views(dqkv, B, N, H, dh)
+    dpk = torch.zeros(2 * N - 1, D, device='cuda')
+    dpq = torch.zeros(2 * N - 1, D, device='cuda')
+    dbias = torch.ones(3 * D, device='cuda')
+    ops.attn_bwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, -1, out, dout, lse,
+                 dq, dk, dv, dqkv.stride(0), dpk, dpq, dbias=dbias)
+    (ref * dout.double().view(B, N, H, dh)).sum().backward()
+    tol = 2e-2
+    assert relerr(dq.reshape(B, N, H, dh), qr.grad) < tol
+    assert relerr(dk.reshape(B, N, H, dh), kr.grad) < tol
+    assert relerr(dv.reshape(B, N, H, dh), vr.grad) < tol
+    assert relerr(dpk.view(-1, H, dh), pkr.grad) < tol
+    assert relerr(dpq.view(-1, H, dh), pqr.grad) < tol
+    db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
+    assert relerr(dbias, db_ref) < tol

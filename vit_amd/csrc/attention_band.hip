@@ -996,13 +996,13 @@ template <int DW, bool BIAS> static void band_bwd_launch(const BandParams& p, in
 bool lai_eligible(const BandParams& p, bool backward);
 void lai_launch(const BandParams& p, bool backward, hipStream_t st);
 bool full_eligible(const BandParams& p, bool backward);
-void full_launch(const BandParams& p, hipStream_t st);
+void full_launch(const BandParams& p, bool backward, hipStream_t st);
 
 // Returns true when a backward launch has already produced the table gradients (p.dpk / p.dpq).
 bool band_launch(const BandParams& p, bool backward, hipStream_t st) {
-    if (full_eligible(p, backward)) {    // unmasked + disentangled, forward: whole score rows in registers (attention_lai.hip)
-        full_launch(p, st);
-        return false;
+    if (full_eligible(p, backward)) {    // unmasked + disentangled: whole score rows per lane, Bias / P / dS in one LDS array (attention_lai.hip)
+        full_launch(p, backward, st);
+        return false;                    // (backward: the table gradients are left to attn_bwd_relds_kernel, from the dS tiles)
     }
     if (lai_eligible(p, backward)) {     // banded (with or without the disentangled tables), one chunk, head width 64 (attention_lai.hip)
         lai_launch(p, backward, st);

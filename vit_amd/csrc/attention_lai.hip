@@ -614,6 +614,395 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
     }
 }
 
+// --------------------------------------------------------------------------- backward, unmasked stage
+// Same layout.  The [N][N] bf16 array is used three times per head, in place:
+//   1. Bias, built as in the forward;
+//   2. phase B (wave = query tile, lane = query): scores from K / Bias, P = exp2(s - lse) -- stored OVER the Bias row it
+//      came from (one 8-byte store per tile), dP = dO V^T, dS = P (dP scale - delta scale), dQ += dS K (registers);
+//   3. phase C (wave = key tile, lane = key; Q and dO images): P read back column-wise, dP again (2 MFMAs: no exp, no
+//      score product), dS -- stored over P, and as a 16 x 16 tile to the workspace attn_bwd_relds_kernel reads -- ,
+//      dV += P^T dO, dK += dS^T Q;
+//   then one more pass of the table tiles for the position terms, read from the dS array along its diagonals
+//      dQ_i += sum_t dS[i][i - t + N - 1] Pk[t]   (first 7 rounds)      dK_j += sum_t dS[j + t - N + 1][j] Pq[t]   (last 7):
+//   every round holds exactly two tiles of each wave's strip = one 32-deep MFMA block (8 two-byte LDS reads for the dS
+//   fragment, 4 K-major table fragments, 4 MFMAs).
+// The table gradients stay with attn_bwd_relds_kernel (its 2 x 104 accumulator tiles per head do not fit this kernel's
+// registers); dropout on the probabilities stays with attention_band.hip.
+__device__ __forceinline__ void lai_colsum(const f32x4 (&acc)[4], float* dst, int g, int li);
+constexpr int FULLB_LDJ = 208;                  // 13 x 16 key columns, no pad (the 1.5 KiB are the lse / delta rows and column sums)
+static size_t full_bwd_bytes(int N) {
+    const LaiGeom G = lai_geom(N, 0);
+    return (size_t)2 * G.NR * LAI_ASTR * 2 + (size_t)2 * FULL_TBUF * 2 + (size_t)N * FULLB_LDJ * 2 + (size_t)G.NR * 4 +
+           3 * 64 * 4 + 64 * 2;
+}
+
+__global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandParams p, int groups) {
+    using T = __bf16;
+    constexpr int ASTR = LAI_ASTR, LDJ = FULLB_LDJ, NTC = LAI_MAXNT, NP = (NTC + 1) / 2;
+    constexpr int NRND = (2 * LAI_MAXNT + FULL_TPR - 1) / FULL_TPR;      // 7 rounds per table
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N;
+    const LaiGeom G = lai_geom(N, 0);
+    const int NT = G.NT, NR = G.NR;
+    const int h = blockIdx.x;
+
+    T* img0 = reinterpret_cast<T*>(smem);                 // K, then Q
+    T* img1 = img0 + NR * ASTR;                           // V, then dO
+    T* tbuf = img1 + NR * ASTR;                           // two table buffers
+    T* Pm = tbuf + 2 * FULL_TBUF;                         // [N][LDJ]: Bias, then P, then dS
+    float* dls = reinterpret_cast<float*>(Pm + N * LDJ);  // [NR]: delta_i * scale
+    float* colacc = dls + NR;                             // [3][64]
+    T* pad = reinterpret_cast<T*>(colacc + 3 * 64);       // [64]: where masked two-byte writes go
+
+    const T* PK = reinterpret_cast<const T*>(p.pk) + h * 64;
+    const T* PQ = reinterpret_cast<const T*>(p.pq) + h * 64;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const bool own = wave < NT;
+    const int R = 2 * N - 1;
+    const int qt = wave;                                  // query tile (phase B) and key tile (phase C) of this wave
+    const int lo_q = qt;
+    const int lo_k = max(0, N - 16 - 16 * qt) >> 4;
+    const int hi_q = (16 * qt + 14 + N) >> 4, hi_k = max(0, 2 * N - 2 - 16 * qt) >> 4;
+
+    // table staging: as in the forward (a cycle of seven pieces per thread, four in flight)
+    const int grp = wave >> 3;
+    const int st_row = (tid & 511) >> 3, st_d = (tid & 7) * 8;
+    auto table_piece = [&](int k) -> u32x4 {
+        const int rnd = 2 * k + grp;
+        const bool second = rnd >= NRND;
+        const int r0 = 16 * ((second ? rnd - NRND : rnd) + NRND * (st_row >> 4)) + (st_row & 15);
+        return lai_load16(second ? PQ : PK, p.ld_p, r0, R, st_d);
+    };
+    T* const st_dst = tbuf + grp * FULL_TBUF + st_row * ASTR + st_d;
+    u32x4 q0 = table_piece(0), q1 = table_piece(1), q2 = table_piece(2), q3 = table_piece(3);
+    int knext = 4;
+    auto stage_next = [&]() {
+        *reinterpret_cast<u32x4*>(st_dst) = q0;
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
+        q3 = table_piece(knext);
+        knext = knext == NRND - 1 ? 0 : knext + 1;
+    };
+    if (tid < 3 * 64) colacc[tid] = 0.f;
+
+    for (int b = blockIdx.y; b < p.B; b += groups) {
+        const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * N * p.ld + h * 64;
+        const T* K = reinterpret_cast<const T*>(p.k) + (long)b * N * p.ld + h * 64;
+        const T* V = reinterpret_cast<const T*>(p.v) + (long)b * N * p.ld + h * 64;
+        const T* dO = reinterpret_cast<const T*>(p.dout) + (long)b * N * p.ldo + h * 64;
+        const T* O = reinterpret_cast<const T*>(p.out) + (long)b * N * p.ldo + h * 64;
+        const float* lse = p.lse + ((long)b * p.H + h) * N;
+        __bf16* ds_head = p.ds_ws + ((long)b * p.H + h) * (2 * NT - 1) * NT * 256;       // this head's dS tiles (cmax = NT - 1)
+        int stid = tid;
+        asm volatile("" : "+v"(stid));                    // per-thread offsets are made per head (as in attn_bwd_lai_kernel)
+        const int lane = stid & 63, g = lane >> 4, li = lane & 15;
+        const int row = 16 * wave + li;                   // the query (phase B) / key (phase C) of this lane
+        const int fr = own ? row : -1;
+        const int rown = min(row, N - 1);
+        const int rowb = li * ASTR + 8 * g, colb = (4 * g + (li >> 2)) * ASTR + 4 * (li & 3);
+
+        // ---- own rows; K, V images; lse and delta rows ---------------------------------------------------------
+        Frag<T> qf[2], dof[2], kfo[2], vfo[2];
+        float dlt = 0.f, l2 = 0.f;
+        {
+            Frag<T> of[2];
+            lai_row_frags(kfo, K, p.ld, fr, N, lane);
+            lai_row_frags(vfo, V, p.ld, fr, N, lane);
+            lai_row_frags(qf, Q, p.ld, fr, N, lane);
+            lai_row_frags(dof, dO, p.ldo, fr, N, lane);
+            lai_row_frags(of, O, p.ldo, fr, N, lane);
+            const float lraw = lse[rown];
+            if (own) {
+                lai_put_rows(img0, kfo, row, lane);
+                lai_put_rows(img1, vfo, row, lane);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dlt += (float)dof[kb].v[e] * (float)of[kb].v[e];
+                dlt += __shfl_xor(dlt, 16, 64);
+                dlt += __shfl_xor(dlt, 32, 64);           // delta_i = dO_i . O_i
+                l2 = row < N ? lraw * LOG2E : INFINITY;     // (a query past the sequence: every probability 0)
+                if (g == 0) dls[row] = dlt * p.scale;
+            }
+        }
+        const int jb = row < N ? row + N - 1 - 4 * g : -(1 << 20);           // j of (t = 4g, r = 0) for this query
+        const int ib = row < N ? row - (N - 1) + 4 * g : -(1 << 20);         // i of (t = 4g, r = 0) for this key
+        T* const c2p_b = Pm + rown * LDJ + (rown + N - 1 - 4 * g) - 3;
+        T* const p2c_b = Pm + (rown - (N - 1) + 4 * g) * LDJ + rown;
+        T* const padp = pad + lane;
+
+        // ---- Bias (as in the forward) ------------------------------------------------------------------------------
+        auto bias_round = [&](int rnd, const T* tb) {
+            if (!own) return;
+            const bool second = rnd >= NRND;
+            const int rho = second ? rnd - NRND : rnd;
+            if (!second) {
+                T* cb = c2p_b - 16 * rho;
+                const int j0 = jb - 16 * rho;
+#pragma unroll
+                for (int u = 0; u < FULL_TPR; ++u) {
+                    const int tt = rho + NRND * u;
+                    if (tt < lo_q || tt > hi_q) continue;
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        Frag<T> a;
+                        frag_load(a, tb + u * (16 * ASTR) + rowb + 32 * kb);
+                        x = mma(a, qf[kb], x);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        T* e = (unsigned)(j0 - 16 * NRND * u - r) < (unsigned)N ? cb + (3 - r - 16 * NRND * u) : padp;
+                        *e = (T)x[r];
+                    }
+                }
+            } else {
+                T* pb = p2c_b + 16 * rho * LDJ;
+                const int i0 = ib + 16 * rho;
+#pragma unroll
+                for (int u = 0; u < FULL_TPR; ++u) {
+                    const int tt = rho + NRND * u;
+                    if (tt < lo_k || tt > hi_k) continue;
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        Frag<T> a;
+                        frag_load(a, tb + u * (16 * ASTR) + rowb + 32 * kb);
+                        x = mma(a, kfo[kb], x);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        T* e = (unsigned)(i0 + 16 * NRND * u + r) < (unsigned)N ? pb + (16 * NRND * u + r) * LDJ : padp;
+                        *e = (T)((float)*e + x[r]);
+                    }
+                }
+            }
+        };
+        if (grp == 0) stage_next();
+        lai_barrier();
+#pragma nounroll
+        for (int it = 0; it < NRND; ++it) {
+            bias_round(2 * it, tbuf);
+            if (grp == 1) stage_next();
+            lai_barrier();
+            bias_round(2 * it + 1, tbuf + FULL_TBUF);
+            if (grp == 0 && it + 1 < NRND) stage_next();
+            lai_barrier();
+        }
+
+        // ---- phase B: query-stationary: P over Bias, dQ (content part) --------------------------------------------
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (own) {
+            const float dls_own = dlt * p.scale;
+            T* brow = Pm + rown * LDJ + 4 * g;
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) {
+                f32x4 dsv[2];
+                int ktc[2] = {0, 0};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kt = 2 * pi + u;
+                    dsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (kt >= NTC) {
+                        ktc[u] = ktc[0];
+                        continue;
+                    }
+                    ktc[u] = min(kt, NT - 1);
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        Frag<T> kr, vr;
+                        lai_rfrag(kr, img0, rowb, ktc[u], kb);
+                        lai_rfrag(vr, img1, rowb, ktc[u], kb);
+                        s = mma(kr, qf[kb], s);           // raw[query li][key 16 kt + 4g + r]
+                        dp = mma(vr, dof[kb], dp);        // dP[query li][key ..]
+                    }
+                    const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(brow + 16 * kt);
+                    bf16x4 p4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = 16 * kt + 4 * g + r < N;
+                        const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(s[r] + (float)b4[r], sc2, -l2) : -INFINITY);
+                        p4[r] = (T)pe;
+                        dsv[u][r] = pe * fmaf(dp[r], p.scale, -dls_own);
+                    }
+                    if (row < N) *reinterpret_cast<bf16x4*>(brow + 16 * kt) = p4;      // P over the Bias it was made from
+                }
+                Frag<T> bs;
+                acc_to_frag(bs, dsv[0], dsv[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {          // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+                    Frag<T> a;
+                    lai_cfrag(a, img0, colb, ktc[0], ktc[1], dt);
+                    dq[dt] = mma(a, bs, dq[dt]);
+                }
+            }
+        }
+        lai_barrier();
+        // ---- Q, dO replace K, V (from the registers that hold them) ---------------------------------------------
+        if (own) {
+            lai_put_rows(img0, qf, row, lane);
+            lai_put_rows(img1, dof, row, lane);
+        }
+        lai_barrier();
+
+        // ---- phase C: key-stationary: dS over P (and to the workspace), dV, dK (content part) ----------------------
+        f32x4 dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (own) {
+            const int kt = wave;
+            f32x4 dv[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            T* pcol = Pm + (4 * g) * LDJ + row;           // P[i = 4g (+ 16 qt + r)][j = row]; row <= 207 < LDJ
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) {
+                f32x4 pt[2], dsv[2];
+                int qtc[2] = {0, 0};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qq = 2 * pi + u;
+                    pt[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (qq >= NTC) {
+                        qtc[u] = qtc[0];
+                        continue;
+                    }
+                    qtc[u] = min(qq, NT - 1);
+                    if (qq >= NT) continue;               // (wave-uniform) no such query tile
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        Frag<T> dor;
+                        lai_rfrag(dor, img1, rowb, qq, kb);
+                        dp = mma(dor, vfo[kb], dp);       // dP[query 16 qq + 4g + r][key li]
+                    }
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dls + 16 * qq + 4 * g);
+                    const int i0 = 16 * qq + 4 * g;
+                    bf16x4 ds4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = i0 + r < N;
+                        T* e = ok ? pcol + (16 * qq + r) * LDJ : padp;
+                        const float pe = ok ? (float)*e : 0.f;
+                        const float d = pe * fmaf(dp[r], p.scale, -d4[r]);
+                        *e = (T)d;                        // dS over P
+                        pt[u][r] = pe;
+                        dsv[u][r] = d;
+                        ds4[r] = (T)d;
+                    }
+                    // the tile attn_bwd_relds_kernel reads: entry (c + cmax, kt), lane l holds dS[4 (l >> 4) + r][l & 15]
+                    *reinterpret_cast<bf16x4*>(ds_head + ((long)(qq - kt + NT - 1) * NT + kt) * 256 + lane * 4) = ds4;
+                }
+                Frag<T> bp, bs;
+                acc_to_frag(bp, pt[0], pt[1]);
+                acc_to_frag(bs, dsv[0], dsv[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Frag<T> a;
+                    lai_cfrag(a, img1, colb, qtc[0], qtc[1], dt);
+                    dv[dt] = mma(a, bp, dv[dt]);          // dV^T[d][key] += dO^T[d][q] P[q][key]
+                    lai_cfrag(a, img0, colb, qtc[0], qtc[1], dt);
+                    dk[dt] = mma(a, bs, dk[dt]);          // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                }
+            }
+            if (row < N) {
+                T* dV = reinterpret_cast<T*>(p.dv) + ((long)b * N + row) * p.ld_d + h * 64;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<bf16x4*>(dV + 16 * dt + 4 * g) =
+                        bf16x4{(__bf16)dv[dt][0], (__bf16)dv[dt][1], (__bf16)dv[dt][2], (__bf16)dv[dt][3]};
+            }
+            if (p.dbias) lai_colsum(dv, colacc + 128, g, li);
+        }
+
+        // ---- position terms: one more cycle of the table tiles against the dS array ---------------------------------
+        auto pos_round = [&](int rnd, const T* tb) {
+            if (!own) return;
+            const bool second = rnd >= NRND;
+            const int rho = second ? rnd - NRND : rnd;
+            const int lo = second ? lo_k : lo_q;
+            // the two tiles of this round inside the strip: rho + 7 ua, rho + 7 (ua + 1)
+            const int ua = lo > rho ? (lo - rho + NRND - 1) / NRND : 0;
+            const int ta = rho + NRND * ua;
+            Frag<T> bf;
+            if (!second) {
+                // dC2P[i][t] = dS[i][i - t + N - 1]: k = 4g + e of tile ta (e < 4), of tile ta + 7 (e >= 4)
+                const T* rowp = Pm + rown * LDJ;
+                const int ja = jb - 16 * ta;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = ja - (e < 4 ? e : 16 * NRND + e - 4);
+                    const T v = rowp[min(max(j, 0), LDJ - 1)];
+                    bf.v[e] = (unsigned)j < (unsigned)N ? v : (T)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Frag<T> a;
+                    lai_cfrag(a, tb, colb, ua, ua + 1, dt);
+                    dq[dt] = mma(a, bf, dq[dt]);          // dQ^T[d][query] += Pk^T[d][t] dC2P^T[t][query]
+                }
+            } else {
+                const T* colp = Pm + rown;
+                const int ia = ib + 16 * ta;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = ia + (e < 4 ? e : 16 * NRND + e - 4);
+                    const T v = colp[min(max(i, 0), N - 1) * LDJ];
+                    bf.v[e] = (unsigned)i < (unsigned)N ? v : (T)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Frag<T> a;
+                    lai_cfrag(a, tb, colb, ua, ua + 1, dt);
+                    dk[dt] = mma(a, bf, dk[dt]);          // dK^T[d][key] += Pq^T[d][t] dP2C^T[t][key]
+                }
+            }
+        };
+        if (grp == 0) stage_next();
+        lai_barrier();            // (also: every wave's dS is in the array)
+#pragma nounroll
+        for (int it = 0; it < NRND; ++it) {
+            pos_round(2 * it, tbuf);
+            if (grp == 1) stage_next();
+            lai_barrier();
+            pos_round(2 * it + 1, tbuf + FULL_TBUF);
+            if (grp == 0 && it + 1 < NRND) stage_next();
+            lai_barrier();
+        }
+        if (own) {
+            if (row < N) {
+                T* dQ = reinterpret_cast<T*>(p.dq) + ((long)b * N + row) * p.ld_d + h * 64;
+                T* dK = reinterpret_cast<T*>(p.dk) + ((long)b * N + row) * p.ld_d + h * 64;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<bf16x4*>(dQ + 16 * dt + 4 * g) =
+                        bf16x4{(__bf16)dq[dt][0], (__bf16)dq[dt][1], (__bf16)dq[dt][2], (__bf16)dq[dt][3]};
+                    *reinterpret_cast<bf16x4*>(dK + 16 * dt + 4 * g) =
+                        bf16x4{(__bf16)dk[dt][0], (__bf16)dk[dt][1], (__bf16)dk[dt][2], (__bf16)dk[dt][3]};
+                }
+            }
+            if (p.dbias) {
+                lai_colsum(dq, colacc, g, li);
+                lai_colsum(dk, colacc + 64, g, li);
+            }
+        }
+        // (the next head's first LDS writes -- K, V images, lse rows -- come after this loop's last barrier; its Bias
+        // writes after two more)
+    }
+    lai_barrier();
+    if (p.dbias && tid < 3 * 64) {
+        const int which = tid >> 6, d = tid & 63;
+        atomicAdd(p.dbias + (long)which * p.H * 64 + h * 64 + d, colacc[tid]);
+    }
+}
+
 // ----------------------------------------------------------------------------------------- backward
 // column sums of a [64 d][16 rows] accumulator set over its 16 row lanes, += dst[d] (LDS)
 __device__ __forceinline__ void lai_colsum(const f32x4 (&acc)[4], float* dst, int g, int li) {
@@ -990,11 +1379,30 @@ bool full_eligible(const BandParams& p, bool backward) {
     }();
     // (short heads: the 13 score tiles a lane carries would be mostly padding; dropout on the probabilities: the mask
     // hashes beside 52 score registers spill -- both stay on attention_band.hip)
-    if (backward || !enabled || p.pk == nullptr || p.dh != 64 || p.N > 16 * LAI_MAXNT || p.N <= 128) return false;
+    if (!enabled || p.pk == nullptr || p.dh != 64 || p.N > 16 * LAI_MAXNT || p.N <= 128) return false;
     if (p.drop.thresh != 0 || (p.w >= 0 && p.w < p.N - 1)) return false;
+    if (backward) {
+        static const bool bwd_enabled = [] {
+            const char* e = getenv("VITK_ATTN_FULL_BWD");
+            return !(e && e[0] == '0');
+        }();
+        // a key tile's table strip (rows N - 16 - 16 kt .. 2N - 2 - 16 kt) must span at most 14 tiles: the position
+        // pass pairs exactly two tiles of a strip per round (201+ tokens span 15: attention_band.hip)
+        return bwd_enabled && p.ds_ws != nullptr && (p.N & 15) + p.N <= 209 && full_bwd_bytes(p.N) <= 160 * 1024;
+    }
     return full_fwd_bytes(p.N) <= 160 * 1024;          // up to 201 tokens
 }
-void full_launch(const BandParams& p, hipStream_t st) {
+void full_launch(const BandParams& p, bool backward, hipStream_t st) {
+    if (backward) {
+        int groups = 256 / p.H;
+        if (groups < 1) groups = 1;
+        if (groups > p.B) groups = p.B;
+        if (groups > 65535) groups = 65535;
+        const size_t lds = full_bwd_bytes(p.N);
+        (void)vitk_lds_optin((const void*)attn_bwd_full_kernel, lds);
+        hipLaunchKernelGGL(attn_bwd_full_kernel, dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        return;
+    }
     int groups = 256 / p.H;
     if (groups < 1) groups = 1;
     if (groups > p.B) groups = p.B;
