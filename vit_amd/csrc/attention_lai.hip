@@ -363,9 +363,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_lai_kernel(const BandPar
 // The tables do not fit beside it (2 x 56 KiB): their tiles pass through two 4-tile buffers, 7 rounds per table, every wave
 // taking the tiles of its strip as they come by (one workgroup barrier per round; the next round's rows are in flight
 // from L2 meanwhile).  attention_band.hip forms the same products per 16 x 16 tile PAIR (8 MFMAs, 4 LDS stores, 8 LDS
-// loads and two intra-wave hand-offs per pair): 264 us per layer at the headline shape against 209 here -- of which the Bias
-// strips are 100 (their 2-byte scatter / read-modify-write LDS traffic, 2184 wave instructions per head, not the MFMAs),
-// the score loop + P V 85, row loads, staging and the 16 barriers 40 (tools/lai_phases.sh with VITK_STOP_MACRO=VITK_FULL_STOP).
+// loads and two intra-wave hand-offs per pair): 264 us per layer at the headline shape against 196 here -- of which the Bias
+// strips are ~90 (their 2-byte scatter / read-modify-write LDS traffic, 2184 wave instructions per head, not the MFMAs),
+// the score loop + P V ~80, row loads, staging and the 16 barriers the rest (tools/lai_phases.sh with
+// VITK_STOP_MACRO=VITK_FULL_STOP).
 // Balancing the rounds and dropping the range tests of interior tiles changed nothing: the strips are bound by the
 // latency chain load - MFMA - MFMA - convert - (load - add) - store of each tile with four waves per SIMD.
 #ifndef VITK_FULL_STOP
@@ -429,7 +430,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
         // of them, so every wave has two tiles of work in every round (with four CONSECUTIVE tiles per round the middle
         // rounds had all waves on four tiles and the outer ones almost none: 49 against 3 wave-tiles)
         const int r0 = 16 * ((second ? rnd - NRND : rnd) + NRND * (st_row >> 4)) + (st_row & 15);
-        return lai_load16(second ? PQ : PK, p.ld_p, r0, R, st_d);
+        // rows past the table: the last row again, NOT zeros -- a select on the loaded value makes the compiler wait for the
+        // load where it is issued (a memory round trip per round: 0.65 us x 28); those rows only ever meet dS / Bias
+        // entries that the range tests leave out
+        return *reinterpret_cast<const u32x4*>((second ? PQ : PK) + (long)min(r0, R - 1) * p.ld_p + st_d);
     };
     T* const st_dst = tbuf + grp * FULL_TBUF + st_row * ASTR + st_d;      // even rounds -> buffer 0, odd rounds -> buffer 1
 
@@ -628,7 +632,13 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
 //   fragment, 4 K-major table fragments, 4 MFMAs).
 // The table gradients stay with attn_bwd_relds_kernel (its 2 x 104 accumulator tiles per head do not fit this kernel's
 // registers); dropout on the probabilities stays with attention_band.hip.
+// Measured at the headline shape (128 x 16 heads x 197 tokens): 462 us + 186 us of attn_bwd_relds_kernel against 885 us for
+// attn_bwd_band_kernel + attn_bwd_relds_kernel; by leaving one phase out (VITK_FULLB_STOP): Bias 58, phase B 69, phase C 113
+// (its column-wise two-byte reads and writes of the array), position pass 62 us.
 __device__ __forceinline__ void lai_colsum(const f32x4 (&acc)[4], float* dst, int g, int li);
+#ifndef VITK_FULLB_STOP
+#define VITK_FULLB_STOP 0            // timing experiments: bit 0 skips the Bias products, 1 phase B, 2 phase C, 3 the position pass
+#endif
 constexpr int FULLB_LDJ = 208;                  // 13 x 16 key columns, no pad (the 1.5 KiB are the lse / delta rows and column sums)
 static size_t full_bwd_bytes(int N) {
     const LaiGeom G = lai_geom(N, 0);
@@ -673,7 +683,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
         const int rnd = 2 * k + grp;
         const bool second = rnd >= NRND;
         const int r0 = 16 * ((second ? rnd - NRND : rnd) + NRND * (st_row >> 4)) + (st_row & 15);
-        return lai_load16(second ? PQ : PK, p.ld_p, r0, R, st_d);
+        // rows past the table: the last row again, NOT zeros -- a select on the loaded value makes the compiler wait for the
+        // load where it is issued (a memory round trip per round: 0.65 us x 28); those rows only ever meet dS / Bias
+        // entries that the range tests leave out
+        return *reinterpret_cast<const u32x4*>((second ? PQ : PK) + (long)min(r0, R - 1) * p.ld_p + st_d);
     };
     T* const st_dst = tbuf + grp * FULL_TBUF + st_row * ASTR + st_d;
     u32x4 q0 = table_piece(0), q1 = table_piece(1), q2 = table_piece(2), q3 = table_piece(3);
@@ -736,7 +749,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
 
         // ---- Bias (as in the forward) ------------------------------------------------------------------------------
         auto bias_round = [&](int rnd, const T* tb) {
-            if (!own) return;
+            if (!own || (VITK_FULLB_STOP & 1)) return;
             const bool second = rnd >= NRND;
             const int rho = second ? rnd - NRND : rnd;
             if (!second) {
@@ -797,7 +810,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (own) {
+        if (own && !(VITK_FULLB_STOP & 2)) {
             const float dls_own = dlt * p.scale;
             T* brow = Pm + rown * LDJ + 4 * g;
 #pragma unroll
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
         f32x4 dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (own) {
+        if (own && !(VITK_FULLB_STOP & 4)) {
             const int kt = wave;
             f32x4 dv[4];
 #pragma unroll
@@ -924,7 +937,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
 
         // ---- position terms: one more cycle of the table tiles against the dS array ---------------------------------
         auto pos_round = [&](int rnd, const T* tb) {
-            if (!own) return;
+            if (!own || (VITK_FULLB_STOP & 8)) return;
             const bool second = rnd >= NRND;
             const int rho = second ? rnd - NRND : rnd;
             const int lo = second ? lo_k : lo_q;
