@@ -178,48 +178,51 @@ def test_lai_plain_kernels(B, N, H, dh, w):
     assert relerr(dbias, db_ref) < tol
 
 
+@pytest.mark.parametrize('bias', [True, False], ids=['dis', 'plain'])
 @pytest.mark.parametrize('B,N,H,dh', [(2, 197, 2, 64), (1, 201, 3, 64), (3, 130, 2, 64), (20, 150, 16, 64), (128, 197, 16, 64)])
-def test_full_dis_forward(B, N, H, dh):
-    """Unmasked disentangled forward on the per-head kernel (whole score rows in registers, position terms summed into one
-    bf16 array per head): output and lse against fp64 (the last case is BASELINE.json's full shape)."""
+def test_full_forward(B, N, H, dh, bias):
+    """Unmasked forward on the per-head kernel (whole score rows in registers; with tables the position terms summed into
+    one bf16 array per head): output and lse against fp64 (the last case is BASELINE.json's full shape)."""
     from vit_amd import ops
     dtype = torch.bfloat16
     D = H * dh
-    qkv, pk, pq = make(B, N, H, dh, dtype, True, seed=3 * N + 1)
+    qkv, pk, pq = make(B, N, H, dh, dtype, bias, seed=3 * N + 1)
     q, k, v = views(qkv, B, N, H, dh)
-    scale = (dh * 3) ** -0.5
+    scale = (dh * (3 if bias else 1)) ** -0.5
     out, lse = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, -1)
     f = lambda t: t.double().reshape(B, N, H, dh)
-    ref, lse_ref, _ = attention_ref(f(q), f(k), f(v), pk.double().view(-1, H, dh), pq.double().view(-1, H, dh), scale, -1)
+    ref, lse_ref, _ = attention_ref(f(q), f(k), f(v), pk.double().view(-1, H, dh) if bias else None,
+                                    pq.double().view(-1, H, dh) if bias else None, scale, -1)
     assert relerr(out.view(B, N, H, dh), ref) < 1.5e-2
     assert relerr(lse, lse_ref) < 2e-3
     out2, lse2 = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, N - 1)     # a band that masks nothing
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
 
 
+@pytest.mark.parametrize('bias', [True, False], ids=['dis', 'plain'])
 @pytest.mark.parametrize('B,N,H,dh', [(2, 197, 2, 64), (1, 200, 3, 64), (1, 201, 3, 64), (3, 130, 2, 64), (2, 144, 2, 64), (20, 150, 16, 64),
                                       (128, 197, 16, 64)])        # (201 tokens: forward on the new kernel, backward on attention_band.hip)
-def test_full_dis_backward(B, N, H, dh):
+def test_full_backward(B, N, H, dh, bias):
     """... and its backward (Bias / P / dS in one LDS array; table gradients from the dS tiles it leaves): dq, dk, dv, both
     table gradients and the q/k/v bias sums against fp64 autograd."""
     from vit_amd import ops
     dtype = torch.bfloat16
     D = H * dh
-    qkv, pk, pq = make(B, N, H, dh, dtype, True, seed=3 * N + 2)
+    qkv, pk, pq = make(B, N, H, dh, dtype, bias, seed=3 * N + 2)
     q, k, v = views(qkv, B, N, H, dh)
-    scale = (dh * 3) ** -0.5
+    scale = (dh * (3 if bias else 1)) ** -0.5
     out, lse = ops.attn_fwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, -1)
     f = lambda t: t.double().reshape(B, N, H, dh).clone().requires_grad_(True)
     qr, kr, vr = f(q), f(k), f(v)
-    pkr = pk.double().view(-1, H, dh).clone().requires_grad_(True)
-    pqr = pq.double().view(-1, H, dh).clone().requires_grad_(True)
+    pkr = pk.double().view(-1, H, dh).clone().requires_grad_(True) if bias else None
+    pqr = pq.double().view(-1, H, dh).clone().requires_grad_(True) if bias else None
     ref, _, _ = attention_ref(qr, kr, vr, pkr, pqr, scale, -1)
     g = torch.Generator(device='cuda').manual_seed(17)
     dout = torch.randn(B * N, D, device='cuda', generator=g).to(dtype)
     dqkv = torch.full_like(qkv, float('nan'))
     dq, dk, dv = views(dqkv, B, N, H, dh)
-    dpk = torch.zeros(2 * N - 1, D, device='cuda')
-    dpq = torch.zeros(2 * N - 1, D, device='cuda')
+    dpk = torch.zeros(2 * N - 1, D, device='cuda') if bias else None
+    dpq = torch.zeros(2 * N - 1, D, device='cuda') if bias else None
     dbias = torch.ones(3 * D, device='cuda')
     ops.attn_bwd(q, k, v, B, H, N, dh, qkv.stride(0), pk, pq, D, scale, -1, out, dout, lse,
                  dq, dk, dv, dqkv.stride(0), dpk, dpq, dbias=dbias)
@@ -228,7 +231,8 @@ def test_full_dis_backward(B, N, H, dh):
     assert relerr(dq.reshape(B, N, H, dh), qr.grad) < tol
     assert relerr(dk.reshape(B, N, H, dh), kr.grad) < tol
     assert relerr(dv.reshape(B, N, H, dh), vr.grad) < tol
-    assert relerr(dpk.view(-1, H, dh), pkr.grad) < tol
-    assert relerr(dpq.view(-1, H, dh), pqr.grad) < tol
+    if bias:
+        assert relerr(dpk.view(-1, H, dh), pkr.grad) < tol
+        assert relerr(dpq.view(-1, H, dh), pqr.grad) < tol
     db_ref = torch.cat([t.grad.sum((0, 1)).reshape(-1) for t in (qr, kr, vr)]) + 1.0
     assert relerr(dbias, db_ref) < tol

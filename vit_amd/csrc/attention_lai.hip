@@ -380,7 +380,8 @@ static size_t full_fwd_bytes(int N) {
     return (size_t)2 * G.NR * LAI_ASTR * 2 + (size_t)2 * FULL_TBUF * 2 + (size_t)N * FULL_LDJ * 2;
 }
 
-template <bool DROP>
+// BIAS = false: no relative tables (the unmasked stage of the timm LAI ViT): no Bias array, no table rounds.
+template <bool DROP, bool BIAS>
 __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandParams p, int groups) {
     using T = __bf16;
     constexpr int ASTR = LAI_ASTR, LDJ = FULL_LDJ, NTC = LAI_MAXNT, NP = (NTC + 1) / 2;
@@ -444,7 +445,13 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
         lai_row_frags(nk, Kh + o, p.ld, fr, N, lane);
         lai_row_frags(nv, Vh + o, p.ld, fr, N, lane);
     }
-    u32x4 q0 = table_piece(0), q1 = table_piece(1), q2 = table_piece(2), q3 = table_piece(3);
+    u32x4 q0 = {}, q1 = {}, q2 = {}, q3 = {};
+    if (BIAS) {
+        q0 = table_piece(0);
+        q1 = table_piece(1);
+        q2 = table_piece(2);
+        q3 = table_piece(3);
+    }
     int knext = 4;               // the piece asked for next
     auto stage_next = [&]() {    // this thread's next piece -> its buffer; ask for the one four ahead
         *reinterpret_cast<u32x4*>(st_dst) = q0;
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
             lai_put_rows(Ks, nk, qi, lane);
             lai_put_rows(Vs, nv, qi, lane);
         }
-        if (grp == 0) stage_next();                  // round 0 -> buffer 0
+        if (BIAS && grp == 0) stage_next();          // round 0 -> buffer 0
         lai_barrier();
         // ---- Bias: 2 NRND rounds of 4 table tiles ---------------------------------------------------------------
         // per-lane bases; every element of a round is at a compile-time offset from them.  A query / key past the sequence
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
             }
         };
 #pragma nounroll
-        for (int it = 0; it < NRND; ++it) {
+        for (int it = 0; BIAS && it < NRND; ++it) {
             bias_round(2 * it, tbuf);
             if (grp == 1) stage_next();                          // round 2 it + 1 -> buffer 1 (last read in round 2 it - 1)
             lai_barrier();
@@ -546,7 +553,8 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
                     lai_rfrag(kr, Ks, rowb, ktc, kb);
                     s = mma(kr, qf[kb], s);          // raw[query li][key 16 kt + 4g + r]
                 }
-                const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(brow + 16 * kt);
+                bf16x4 b4 = {};
+                if (BIAS) b4 = *reinterpret_cast<const bf16x4*>(brow + 16 * kt);
                 if (16 * kt + 16 <= N) {             // (scalar branch) a tile inside the sequence: no mask
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sc[kt][r] = (s[r] + (float)b4[r]) * sc2;
@@ -646,6 +654,7 @@ static size_t full_bwd_bytes(int N) {
            3 * 64 * 4 + 64 * 2;
 }
 
+template <bool BIAS>
 __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandParams p, int groups) {
     using T = __bf16;
     constexpr int ASTR = LAI_ASTR, LDJ = FULLB_LDJ, NTC = LAI_MAXNT, NP = (NTC + 1) / 2;
@@ -689,7 +698,13 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
         return *reinterpret_cast<const u32x4*>((second ? PQ : PK) + (long)min(r0, R - 1) * p.ld_p + st_d);
     };
     T* const st_dst = tbuf + grp * FULL_TBUF + st_row * ASTR + st_d;
-    u32x4 q0 = table_piece(0), q1 = table_piece(1), q2 = table_piece(2), q3 = table_piece(3);
+    u32x4 q0 = {}, q1 = {}, q2 = {}, q3 = {};
+    if (BIAS) {
+        q0 = table_piece(0);
+        q1 = table_piece(1);
+        q2 = table_piece(2);
+        q3 = table_piece(3);
+    }
     int knext = 4;
     auto stage_next = [&]() {
         *reinterpret_cast<u32x4*>(st_dst) = q0;
@@ -794,10 +809,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
                 }
             }
         };
-        if (grp == 0) stage_next();
+        if (BIAS && grp == 0) stage_next();
         lai_barrier();
 #pragma nounroll
-        for (int it = 0; it < NRND; ++it) {
+        for (int it = 0; BIAS && it < NRND; ++it) {
             bias_round(2 * it, tbuf);
             if (grp == 1) stage_next();
             lai_barrier();
@@ -835,7 +850,8 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
                         s = mma(kr, qf[kb], s);           // raw[query li][key 16 kt + 4g + r]
                         dp = mma(vr, dof[kb], dp);        // dP[query li][key ..]
                     }
-                    const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(brow + 16 * kt);
+                    bf16x4 b4 = {};
+                    if (BIAS) b4 = *reinterpret_cast<const bf16x4*>(brow + 16 * kt);
                     bf16x4 p4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -911,7 +927,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
                         ds4[r] = (T)d;
                     }
                     // the tile attn_bwd_relds_kernel reads: entry (c + cmax, kt), lane l holds dS[4 (l >> 4) + r][l & 15]
-                    *reinterpret_cast<bf16x4*>(ds_head + ((long)(qq - kt + NT - 1) * NT + kt) * 256 + lane * 4) = ds4;
+                    if (BIAS) *reinterpret_cast<bf16x4*>(ds_head + ((long)(qq - kt + NT - 1) * NT + kt) * 256 + lane * 4) = ds4;
                 }
                 Frag<T> bp, bs;
                 acc_to_frag(bp, pt[0], pt[1]);
@@ -978,10 +994,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
                 }
             }
         };
-        if (grp == 0) stage_next();
-        lai_barrier();            // (also: every wave's dS is in the array)
+        if (BIAS && grp == 0) stage_next();
+        lai_barrier();            // (also: every wave's dS is in the array; without tables: everybody is done with the images)
 #pragma nounroll
-        for (int it = 0; it < NRND; ++it) {
+        for (int it = 0; BIAS && it < NRND; ++it) {
             pos_round(2 * it, tbuf);
             if (grp == 1) stage_next();
             lai_barrier();
@@ -1392,7 +1408,7 @@ bool full_eligible(const BandParams& p, bool backward) {
     }();
     // (short heads: the 13 score tiles a lane carries would be mostly padding; dropout on the probabilities: the mask
     // hashes beside 52 score registers spill -- both stay on attention_band.hip)
-    if (!enabled || p.pk == nullptr || p.dh != 64 || p.N > 16 * LAI_MAXNT || p.N <= 128) return false;
+    if (!enabled || p.dh != 64 || p.N > 16 * LAI_MAXNT || p.N <= 128) return false;
     if (p.drop.thresh != 0 || (p.w >= 0 && p.w < p.N - 1)) return false;
     if (backward) {
         static const bool bwd_enabled = [] {
@@ -1412,8 +1428,13 @@ void full_launch(const BandParams& p, bool backward, hipStream_t st) {
         if (groups > p.B) groups = p.B;
         if (groups > 65535) groups = 65535;
         const size_t lds = full_bwd_bytes(p.N);
-        (void)vitk_lds_optin((const void*)attn_bwd_full_kernel, lds);
-        hipLaunchKernelGGL(attn_bwd_full_kernel, dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        if (p.pk != nullptr) {
+            (void)vitk_lds_optin((const void*)attn_bwd_full_kernel<true>, lds);
+            hipLaunchKernelGGL(attn_bwd_full_kernel<true>, dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        } else {
+            (void)vitk_lds_optin((const void*)attn_bwd_full_kernel<false>, lds);
+            hipLaunchKernelGGL(attn_bwd_full_kernel<false>, dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        }
         return;
     }
     int groups = 256 / p.H;
@@ -1421,8 +1442,13 @@ void full_launch(const BandParams& p, bool backward, hipStream_t st) {
     if (groups > p.B) groups = p.B;
     if (groups > 65535) groups = 65535;
     const size_t lds = full_fwd_bytes(p.N);
-    (void)vitk_lds_optin((const void*)attn_fwd_full_kernel<false>, lds);
-    hipLaunchKernelGGL((attn_fwd_full_kernel<false>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+    if (p.pk != nullptr) {
+        (void)vitk_lds_optin((const void*)attn_fwd_full_kernel<false, true>, lds);
+        hipLaunchKernelGGL((attn_fwd_full_kernel<false, true>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+    } else {
+        (void)vitk_lds_optin((const void*)attn_fwd_full_kernel<false, false>, lds);
+        hipLaunchKernelGGL((attn_fwd_full_kernel<false, false>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+    }
 }
 
 void lai_launch(const BandParams& p, bool backward, hipStream_t st) {
