@@ -129,3 +129,42 @@ def test_full_depth_against_the_oracle(dtype, epoch):
             assert l2 < 4e-2 and mx < 4e-2, (n, report[n])
     # parameters the reference never trains get no gradient here either
     assert sorted(n for n, p in gp.items() if p.grad is None) == sorted(n for n, p in rp.items() if p.grad is None)
+
+
+@pytest.mark.parametrize('epoch', [5, 25, 45], ids=['w8', 'w18', 'unmasked'])
+def test_timm_lai_at_224px_against_the_oracle(epoch):
+    """The timm LAI ViT at its real token count and head width (config 2's shape: 224 px / 16 = 197 tokens, 12 heads of 64,
+    768 wide; four layers keep the CPU oracle short) in bf16 against the oracle: the plain (no relative tables) instances of
+    the per-head attention kernels -- banded (attn_fwd_lai_kernel / attn_bwd_lai_kernel, BIAS = false) in the LAI stages,
+    whole score rows (attn_fwd_full_kernel / attn_bwd_full_kernel, BIAS = false) past the last one -- inside the fused
+    pre-LN block.  Bars as for the other whole-model bf16 tests: logits 2e-2, gradients 4e-2 (measured: logits 0.7-0.8e-2,
+    worst gradient 1.3-1.4e-2 in all three stages)."""
+    sys.path.insert(0, ROOT)
+    from oracle import ref_cpu as R
+    from vit_amd.train import build_model, label_smoothing_ce
+    me = [10, 20, 30, 40]
+    torch.manual_seed(7)
+    net = build_model('transformer_timm_lai', 'S', mask_epochs=me, dtype=torch.bfloat16, depth=4)
+    ref = R.RefVisionTransformerLAI(img_size=224, patch_size=16, num_classes=1000, embed_dim=768, depth=4, num_heads=12,
+                                    mlp_ratio=4.0, mask_epochs=me)
+    ref.load_state_dict({k: v.detach().float().cpu() for k, v in net.state_dict().items()})
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(3, 3, 224, 224, generator=g)
+    tgt = torch.tensor([1, 500, 999])
+    lo_r = ref(img, epoch)
+    R.label_smoothing_ce(lo_r, tgt).backward()
+    lo_g = net(img.cuda(), epoch)
+    label_smoothing_ce(lo_g, tgt.cuda()).backward()
+
+    def maxerr(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+    report = {'logits': maxerr(lo_g.float(), lo_r)}
+    rp = dict(ref.named_parameters())
+    for n, q in net.named_parameters():
+        report[n] = maxerr(q.grad.float(), rp[n].grad)
+    worst = max(report.items(), key=lambda kv: kv[1] if kv[0] != 'logits' else 0.0)
+    print({'logits': report['logits'], 'worst gradient': worst})
+    assert report['logits'] < 2e-2, report['logits']
+    assert worst[1] < 4e-2, worst
