@@ -241,7 +241,11 @@ def side_join(device):
 # library's own splits so that the in-step launch times of the main stream's GEMMs described those kernels alone: 175 us
 # per NT launch against 203 beside the dW GEMMs; bench.py now measures kernel quality in a pass of its own,
 # roofline.isolated, and the step runs the faster schedule).  VITK_DW_SPLITK='' / `bench.py --no-max-overlap`: the old one.
-_DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '16:2,64:2')
+# Swept again at the end of round 3, with the new attention kernels in the step (one box, `tools/runs/r3_run34.sh` /
+# `r3_run35.sh`, img/s): '16:2,64:2' 2092-2099 | proj 16:3 2121, **16:4 2128-2134**, 16:6 2127, 16:8 2123, 16:1 1835 |
+# fc 64:3 2119, 64:4 2059 | qkv 48:2 1977, 48:3 / 48:4 2088 (the library's 5: best).  The proj dW GEMM with four splits (64
+# CUs for half as long) is +1.8 %: the default.
+_DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '16:4,64:2')
 
 
 def _dw_splitk(dy, x):
