@@ -222,7 +222,7 @@ def main():
     ap.add_argument('--no-max-overlap', action='store_true',
                     help='the library\'s own K splits (256 / tiles: 16 / 4 / 4) in the proj / fc1 / fc2 weight-gradient GEMMs and the '
                          'bias-gradient column sums on the main stream, instead of the default throughput schedule (two K splits = '
-                         'VITK_DW_SPLITK=16:4,64:2, the dW GEMMs holding 64 / 128 CUs BESIDE the main stream, column sums on the side '
+                         'VITK_DW_SPLITK=16:4,64:2,36:4, the dW GEMMs holding 64 / 128 CUs BESIDE the main stream, column sums on the side '
                          'stream: +3-4 %% images/s on the headline).  With this flag the in-step launch times describe each kernel '
                          'alone again (round 2\'s default); roofline.isolated measures that directly either way')
     ap.add_argument('--dropout', type=float, default=0.0,

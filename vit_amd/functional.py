@@ -244,8 +244,10 @@ def side_join(device):
 # Swept again at the end of round 3, with the new attention kernels in the step (one box, `tools/runs/r3_run34.sh` /
 # `r3_run35.sh`, img/s): '16:2,64:2' 2092-2099 | proj 16:3 2121, **16:4 2128-2134**, 16:6 2127, 16:8 2123, 16:1 1835 |
 # fc 64:3 2119, 64:4 2059 | qkv 48:2 1977, 48:3 / 48:4 2088 (the library's 5: best).  The proj dW GEMM with four splits (64
-# CUs for half as long) is +1.8 %: the default.
-_DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '16:4,64:2')
+# CUs for half as long) is +1.8 %: the default.  768-wide models (tools/runs/r3_run37.sh): fc1 / fc2 dW (36 tiles) with 4 splits
+# instead of the library's 7: lai_s16 6315-6323 -> 6450, performer_s16_384 2287 -> 2292; proj (9 tiles) and qkv (27): nothing
+# that helps both.
+_DW_SPLITK = os.environ.get('VITK_DW_SPLITK', '16:4,64:2,36:4')
 
 
 def _dw_splitk(dy, x):
