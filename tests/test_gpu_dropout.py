@@ -73,7 +73,7 @@ def test_elementwise_dropout_statistics_and_backward():
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 @pytest.mark.parametrize('B,H,N,dh,w,bias', [(2, 4, 65, 32, 8, True), (2, 4, 197, 64, 20, True), (3, 2, 100, 64, 8, True), (20, 16, 33, 64, 12, True),
-                                                  (1, 2, 197, 64, -1, False),
+                                                  (1, 2, 197, 64, -1, False), (2, 3, 197, 64, -1, True), (3, 2, 150, 64, -1, True), (9, 16, 197, 64, -1, True),
                                             (1, 2, 300, 80, 12, True)])
 def test_attention_prob_dropout_vs_closed_form(B, H, N, dh, w, bias, dtype):
     """Forward and every gradient of the fused attention with dropout on the probabilities, against fp64 math with the

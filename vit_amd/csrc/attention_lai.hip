@@ -570,15 +570,18 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float ls = 0.f;
             const uint64_t drow = DROP ? (dhead + (uint64_t)qin) * (uint64_t)N : 0;
+            // (made per head: as invariants of the batch loop the 52 clamped key indices of the dropout stream are hoisted
+            // out of it, held through everything and spilled -- 125 registers)
+            int g4 = 4 * g;
+            if (DROP) asm volatile("" : "+v"(g4));
 #pragma unroll
             for (int kt = 0; kt < NTC; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(sc[kt][r] - m);
                     ls += pv;
-                    sc[kt][r] = DROP ? pv * drop_mul(p.drop, drow + (uint64_t)(uint32_t)min(16 * kt + 4 * g + r, N - 1)) : pv;
+                    sc[kt][r] = pv;
                 }
-                if (DROP) __builtin_amdgcn_sched_barrier(0);
             }
             ls += __shfl_xor(ls, 16, 64);
             ls += __shfl_xor(ls, 32, 64);
@@ -593,8 +596,20 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_fwd_full_kernel(const BandPa
             for (int pi = 0; pi < NP; ++pi) {
                 constexpr f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                 const int ca = 2 * pi, cb = 2 * pi + 1 < NTC ? 2 * pi + 1 : 2 * pi;
+                f32x4 pa = sc[ca], pb = 2 * pi + 1 < NTC ? sc[cb] : zero4;
+                if (DROP) {
+                    // dropout (reference :915) on the way into P V: the normaliser above keeps every probability; element
+                    // ((b H + h) N + i) N + j of the stream as in the other attention kernels.  One tile pair's hashes at a
+                    // time (hashed in the exp loop, beside 52 live scores, the kernel spilled 153 registers)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pa[r] *= drop_mul(p.drop, drow + (uint64_t)(uint32_t)min(16 * ca + g4 + r, N - 1));
+                        pb[r] *= drop_mul(p.drop, drow + (uint64_t)(uint32_t)min(16 * cb + g4 + r, N - 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 Frag<T> pf;
-                acc_to_frag(pf, sc[ca], 2 * pi + 1 < NTC ? sc[cb] : zero4);
+                acc_to_frag(pf, pa, pb);
                 const int ka = min(ca, NT - 1), kb2 = min(cb, NT - 1);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -654,7 +669,7 @@ static size_t full_bwd_bytes(int N) {
            3 * 64 * 4 + 64 * 2;
 }
 
-template <bool BIAS>
+template <bool BIAS, bool DROP>
 __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandParams p, int groups) {
     using T = __bf16;
     constexpr int ASTR = LAI_ASTR, LDJ = FULLB_LDJ, NTC = LAI_MAXNT, NP = (NTC + 1) / 2;
@@ -724,6 +739,7 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
         const T* O = reinterpret_cast<const T*>(p.out) + (long)b * N * p.ldo + h * 64;
         const float* lse = p.lse + ((long)b * p.H + h) * N;
         __bf16* ds_head = p.ds_ws + ((long)b * p.H + h) * (2 * NT - 1) * NT * 256;       // this head's dS tiles (cmax = NT - 1)
+        const uint64_t dhead = (uint64_t)(b * p.H + h) * (uint64_t)N;      // first row of this head in the dropout stream
         int stid = tid;
         asm volatile("" : "+v"(stid));                    // per-thread offsets are made per head (as in attn_bwd_lai_kernel)
         const int lane = stid & 63, g = lane >> 4, li = lane & 15;
@@ -858,7 +874,10 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
                         const bool ok = 16 * kt + 4 * g + r < N;
                         const float pe = __builtin_amdgcn_exp2f(ok ? fmaf(s[r] + (float)b4[r], sc2, -l2) : -INFINITY);
                         p4[r] = (T)pe;
-                        dsv[u][r] = pe * fmaf(dp[r], p.scale, -dls_own);
+                        // dropout: dP = (dO V^T) * keep / (1 - p); delta is unchanged (O was made from the dropped P)
+                        const float dm = DROP ? drop_mul(p.drop, (dhead + (uint64_t)rown) * (uint64_t)N +
+                                                                     (uint64_t)(uint32_t)min(16 * kt + 4 * g + r, N - 1)) : 1.f;
+                        dsv[u][r] = pe * fmaf(dp[r] * dm, p.scale, -dls_own);
                     }
                     if (row < N) *reinterpret_cast<bf16x4*>(brow + 16 * kt) = p4;      // P over the Bias it was made from
                 }
@@ -920,9 +939,11 @@ __global__ __launch_bounds__(LAI_THREADS) void attn_bwd_full_kernel(const BandPa
                         const bool ok = i0 + r < N;
                         T* e = ok ? pcol + (16 * qq + r) * LDJ : padp;
                         const float pe = ok ? (float)*e : 0.f;
-                        const float d = pe * fmaf(dp[r], p.scale, -d4[r]);
+                        const float dm = DROP ? drop_mul(p.drop, (dhead + (uint64_t)(uint32_t)min(i0 + r, N - 1)) * (uint64_t)N +
+                                                                     (uint64_t)rown) : 1.f;
+                        const float d = pe * fmaf(dp[r] * dm, p.scale, -d4[r]);
                         *e = (T)d;                        // dS over P
-                        pt[u][r] = pe;
+                        pt[u][r] = pe * dm;               // dV sees the dropped probabilities
                         dsv[u][r] = d;
                         ds4[r] = (T)d;
                     }
@@ -1406,10 +1427,9 @@ bool full_eligible(const BandParams& p, bool backward) {
         const char* e = getenv("VITK_ATTN_FULL");
         return !(e && e[0] == '0');
     }();
-    // (short heads: the 13 score tiles a lane carries would be mostly padding; dropout on the probabilities: the mask
-    // hashes beside 52 score registers spill -- both stay on attention_band.hip)
+    // (short heads: the 13 score tiles a lane carries would be mostly padding: they stay on attention_band.hip)
     if (!enabled || p.dh != 64 || p.N > 16 * LAI_MAXNT || p.N <= 128) return false;
-    if (p.drop.thresh != 0 || (p.w >= 0 && p.w < p.N - 1)) return false;
+    if (p.w >= 0 && p.w < p.N - 1) return false;
     if (backward) {
         static const bool bwd_enabled = [] {
             const char* e = getenv("VITK_ATTN_FULL_BWD");
@@ -1428,13 +1448,18 @@ void full_launch(const BandParams& p, bool backward, hipStream_t st) {
         if (groups > p.B) groups = p.B;
         if (groups > 65535) groups = 65535;
         const size_t lds = full_bwd_bytes(p.N);
+#define VITK_FULLB(BI, DR)                                                                                         \
+    do {                                                                                                           \
+        (void)vitk_lds_optin((const void*)attn_bwd_full_kernel<BI, DR>, lds);                                      \
+        hipLaunchKernelGGL((attn_bwd_full_kernel<BI, DR>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups); \
+    } while (0)
+        const bool drop = p.drop.thresh != 0;
         if (p.pk != nullptr) {
-            (void)vitk_lds_optin((const void*)attn_bwd_full_kernel<true>, lds);
-            hipLaunchKernelGGL(attn_bwd_full_kernel<true>, dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+            if (drop) VITK_FULLB(true, true); else VITK_FULLB(true, false);
         } else {
-            (void)vitk_lds_optin((const void*)attn_bwd_full_kernel<false>, lds);
-            hipLaunchKernelGGL(attn_bwd_full_kernel<false>, dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+            if (drop) VITK_FULLB(false, true); else VITK_FULLB(false, false);
         }
+#undef VITK_FULLB
         return;
     }
     int groups = 256 / p.H;
@@ -1442,13 +1467,18 @@ void full_launch(const BandParams& p, bool backward, hipStream_t st) {
     if (groups > p.B) groups = p.B;
     if (groups > 65535) groups = 65535;
     const size_t lds = full_fwd_bytes(p.N);
+#define VITK_FULLF(DR, BI)                                                                                         \
+    do {                                                                                                           \
+        (void)vitk_lds_optin((const void*)attn_fwd_full_kernel<DR, BI>, lds);                                      \
+        hipLaunchKernelGGL((attn_fwd_full_kernel<DR, BI>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups); \
+    } while (0)
+    const bool drop = p.drop.thresh != 0;
     if (p.pk != nullptr) {
-        (void)vitk_lds_optin((const void*)attn_fwd_full_kernel<false, true>, lds);
-        hipLaunchKernelGGL((attn_fwd_full_kernel<false, true>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        if (drop) VITK_FULLF(true, true); else VITK_FULLF(false, true);
     } else {
-        (void)vitk_lds_optin((const void*)attn_fwd_full_kernel<false, false>, lds);
-        hipLaunchKernelGGL((attn_fwd_full_kernel<false, false>), dim3(p.H, groups), dim3(LAI_THREADS), lds, st, p, groups);
+        if (drop) VITK_FULLF(true, false); else VITK_FULLF(false, false);
     }
+#undef VITK_FULLF
 }
 
 void lai_launch(const BandParams& p, bool backward, hipStream_t st) {
